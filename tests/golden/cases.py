@@ -1,0 +1,294 @@
+"""Seeded case definitions shared by make_golden.py (which runs them through the imported
+reference) and the tests (which run them through the oracle / the HIP path and compare with
+the committed outputs).  Inputs are regenerated from seeds; only expected outputs and
+hashes are stored in the fixture files, so the fixtures stay small.
+
+Nothing here imports the reference.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+
+from image_transformation_amd import synthetic  # noqa: E402
+
+GOLDEN_DIR = os.path.dirname(os.path.abspath(__file__))
+BUNDLE_DIR = os.path.join(GOLDEN_DIR, "bundles")
+BUNDLES = ("squarespace", "audio_book")
+
+
+def sha16(arr: np.ndarray) -> str:
+    """First 16 hex chars of SHA-256 over the raw RGBA bytes (as SURVEY.md App. A.6)."""
+    return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()[:16]
+
+
+# ----------------------------------------------------------------------------- composite
+def _solid(w, h, rgba):
+    a = np.empty((h, w, 4), np.uint8)
+    a[:] = np.asarray(rgba, np.uint8)
+    return a
+
+
+def composite_kat_cases() -> List[dict]:
+    """Hand-written known-answer cases (SURVEY.md App. A.6 edge cases + tests/test_compositor.py:5-11)."""
+    red = _solid(10, 10, (255, 0, 0, 255))
+    half_green = _solid(4, 4, (0, 255, 0, 128))
+    cases = [
+        dict(name="ref_test_compositor", bg=red, objects={1: _solid(2, 2, (0, 255, 0, 255))},
+             placements=[{"object_id": 1, "box": [4, 4, 6, 6]}]),
+        dict(name="clip_bottom_right", bg=red, objects={1: half_green},
+             placements=[{"object_id": 1, "box": [8, 8, 12, 12]}]),
+        dict(name="clip_top_left", bg=red, objects={1: half_green},
+             placements=[{"object_id": 1, "box": [-2, -2, 2, 2]}]),
+        dict(name="degenerate_zero", bg=red, objects={1: half_green},
+             placements=[{"object_id": 1, "box": [3, 3, 3, 3]}]),
+        dict(name="degenerate_negative", bg=red, objects={1: half_green},
+             placements=[{"object_id": 1, "box": [5, 5, 4, 4]}]),
+        dict(name="float_box_str_id", bg=red, objects={1: half_green},
+             placements=[{"object_id": "1", "box": [1.9, 1.9, 5.9, 5.9]}]),
+        dict(name="semi_transparent_bg", bg=_solid(10, 10, (10, 20, 30, 100)), objects={1: half_green},
+             placements=[{"object_id": 1, "box": [2, 2, 6, 6]}]),
+        dict(name="unknown_id_skipped", bg=red, objects={1: half_green},
+             placements=[{"object_id": 7, "box": [0, 0, 4, 4]}, {"object_id": 1, "box": [1, 1, 5, 5]}]),
+        dict(name="fully_off_canvas", bg=red, objects={1: half_green},
+             placements=[{"object_id": 1, "box": [20, 20, 24, 24]}, {"object_id": 1, "box": [-9, 3, -5, 7]}]),
+        dict(name="empty_placements", bg=red, objects={1: half_green}, placements=[]),
+        dict(name="same_object_twice_overlap", bg=red, objects={1: half_green},
+             placements=[{"object_id": 1, "box": [2, 2, 6, 6]}, {"object_id": 1, "box": [4, 4, 8, 8]}]),
+    ]
+    return cases
+
+
+def composite_random_case(seed: int) -> dict:
+    """Small random composite: soft alpha, overlaps, clipping on every edge, up/down-scaling,
+    degenerate boxes, optionally a semi-transparent random background."""
+    rng = np.random.default_rng(10_000 + seed)
+    W = int(rng.integers(8, 97))
+    H = int(rng.integers(8, 81))
+    kind = seed % 4
+    if kind == 0:
+        bg = _solid(W, H, tuple(int(v) for v in rng.integers(0, 256, 3)) + (255,))
+    elif kind == 1:
+        bg = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+        bg[:, :, 3] = 255
+    else:
+        bg = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)  # arbitrary alpha: general formula
+    n_obj = int(rng.integers(1, 6))
+    objects: Dict[int, np.ndarray] = {}
+    for i in range(n_obj):
+        w = int(rng.integers(1, 41))
+        h = int(rng.integers(1, 41))
+        mode = ("soft", "binary", "opaque")[int(rng.integers(0, 3))]
+        objects[i + 1] = synthetic.make_cutout(rng, w, h, mode)
+    placements = []
+    for _ in range(int(rng.integers(1, 9))):
+        oid = int(rng.integers(1, n_obj + 1))
+        sh, sw = objects[oid].shape[:2]
+        mode = int(rng.integers(0, 4))
+        if mode == 0:      # identity size (the Flex pipeline's only case)
+            w, h = sw, sh
+        elif mode == 1:    # arbitrary rescale
+            w = int(rng.integers(1, 61))
+            h = int(rng.integers(1, 61))
+        elif mode == 2:    # one axis unchanged
+            w, h = sw, int(rng.integers(1, 61))
+        else:
+            w, h = int(rng.integers(1, 61)), sh
+        x1 = int(rng.integers(-w, W + 1))
+        y1 = int(rng.integers(-h, H + 1))
+        placements.append({"object_id": oid, "box": [x1, y1, x1 + w, y1 + h]})
+    return dict(name=f"random_{seed}", bg=bg, objects=objects, placements=placements)
+
+
+N_COMPOSITE_RANDOM = 48
+
+
+def composite_cases() -> List[dict]:
+    return composite_kat_cases() + [composite_random_case(s) for s in range(N_COMPOSITE_RANDOM)]
+
+
+# ----------------------------------------------------------------------------- resize
+RESIZE_SHAPES: List[Tuple[Tuple[int, int], Tuple[int, int]]] = [
+    # (src w,h) -> (dst w,h)
+    ((37, 21), (12, 7)), ((12, 7), (37, 21)), ((64, 48), (64, 20)), ((64, 48), (20, 48)),
+    ((100, 80), (26, 21)), ((13, 3), (30, 7)), ((23, 6), (12, 12)), ((1, 1), (5, 4)),
+    ((5, 4), (1, 1)), ((2, 50), (9, 9)), ((50, 2), (9, 9)), ((31, 31), (32, 32)),
+    ((200, 150), (7, 5)), ((3, 2), (50, 40)), ((97, 89), (96, 88)), ((40, 30), (40, 30)),
+]
+
+
+def resize_case(idx: int) -> dict:
+    (sw, sh), (dw, dh) = RESIZE_SHAPES[idx]
+    rng = np.random.default_rng(20_000 + idx)
+    src = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
+    # premultiply / unpremultiply edge alphas
+    edge = np.asarray([0, 1, 2, 127, 128, 254, 255], np.uint8)
+    pick = rng.integers(0, 3, (sh, sw))
+    src[:, :, 3] = np.where(pick == 0, edge[rng.integers(0, len(edge), (sh, sw))], src[:, :, 3])
+    return dict(name=f"resize_{sw}x{sh}_to_{dw}x{dh}", src=src, size=(dw, dh))
+
+
+# ----------------------------------------------------------------------------- median
+def median_case(idx: int) -> dict:
+    rng = np.random.default_rng(30_000 + idx)
+    kinds = ["random", "even_count", "odd_count", "all_transparent", "single_opaque", "two_values",
+             "skewed", "one_pixel"]
+    kind = kinds[idx % len(kinds)]
+    h, w = int(rng.integers(3, 70)), int(rng.integers(3, 70))
+    a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    if kind == "even_count":
+        a[:, :, 3] = 0
+        flat = a.reshape(-1, 4)
+        flat[: 2 * (len(flat) // 4), 3] = 200
+    elif kind == "odd_count":
+        a[:, :, 3] = 0
+        flat = a.reshape(-1, 4)
+        flat[: 2 * (len(flat) // 4) + 1, 3] = 1
+    elif kind == "all_transparent":
+        a[:, :, 3] = 0
+    elif kind == "single_opaque":
+        a[:, :, 3] = 0
+        a[h // 2, w // 2, 3] = 255
+    elif kind == "two_values":
+        a[:, :, :3] = np.where(rng.integers(0, 2, (h, w, 1)) == 0, 10, 11).astype(np.uint8)
+        a[:, :, 3] = 255
+    elif kind == "skewed":
+        a[:, :, :3] = (rng.integers(0, 256, (h, w, 3)) ** 2 // 255).astype(np.uint8)
+    elif kind == "one_pixel":
+        a = a[:1, :1].copy()
+    return dict(name=f"median_{idx}_{kind}", rgba=np.ascontiguousarray(a))
+
+
+N_MEDIAN = 24
+
+
+# ----------------------------------------------------------------------------- flex trees
+JUSTIFY = ["start", "center", "end", "space_between", "space_around"]
+ALIGN = ["start", "center", "end"]
+
+
+def _rand_object_node(rng, oid, exotic: bool) -> dict:
+    node: dict = {"object_id": oid}
+    if rng.random() < 0.2:
+        node["object_id"] = str(oid)  # int-like strings are accepted (int())
+    if rng.random() < 0.3:
+        node["name"] = f"obj{oid}"
+    r = rng.random()
+    if r < 0.2:
+        node["padding_px"] = int(rng.integers(0, 25))
+    elif r < 0.4:
+        node["padding_px"] = {k: int(rng.integers(0, 30)) for k in ("left", "right", "top", "bottom")
+                              if rng.random() < 0.6}
+    if exotic:
+        if rng.random() < 0.4:
+            pin = {}
+            if rng.random() < 0.7:
+                pin["horizontal"] = ALIGN[int(rng.integers(0, 3))]
+            if rng.random() < 0.7:
+                pin["vertical"] = ALIGN[int(rng.integers(0, 3))]
+            node["pin"] = pin
+        if rng.random() < 0.4:
+            node["offset_px"] = {k: int(rng.integers(-40, 41)) for k in ("x", "y") if rng.random() < 0.7}
+        if rng.random() < 0.4:
+            edges = []
+            if rng.random() < 0.6:
+                edges.append(["left", "right", "LEFT"][int(rng.integers(0, 3))])
+            if rng.random() < 0.6 or not edges:
+                edges.append(["top", "bottom"][int(rng.integers(0, 2))])
+            st = {"edges": edges}
+            if rng.random() < 0.6:
+                st["margin_px"] = int(rng.integers(0, 20))
+            node["stick_to"] = st
+    return node
+
+
+def _rand_container(rng, ids: List[int], depth: int, exotic: bool) -> dict:
+    node: dict = {"type": "flex"}
+    r = rng.random()
+    if r < 0.45:
+        node["direction"] = "row"
+    elif r < 0.9:
+        node["direction"] = "column"
+    elif r < 0.95:
+        node["direction"] = "diagonal"  # unknown -> column branch
+    r = rng.random()
+    if r < 0.8:
+        node["justify"] = JUSTIFY[int(rng.integers(0, 5))]
+    elif r < 0.87:
+        node["justify"] = "stretch"  # unknown -> start
+    r = rng.random()
+    if r < 0.8:
+        node["align"] = ALIGN[int(rng.integers(0, 3))]
+    elif r < 0.87:
+        node["align"] = "baseline"  # unknown -> center
+    if rng.random() < 0.6:
+        node["gap_px"] = int(rng.integers(0, 41))
+        if exotic and rng.random() < 0.15:
+            node["gap_px"] = [-7, 3.9, "12"][int(rng.integers(0, 3))]  # int() coercion
+    if rng.random() < 0.5:
+        node["padding_px"] = int(rng.integers(0, 31))
+        if exotic and rng.random() < 0.1:
+            node["padding_px"] = -5
+    children = []
+    remaining = list(ids)
+    while remaining:
+        if depth < 2 and len(remaining) >= 2 and rng.random() < 0.4:
+            take = int(rng.integers(1, len(remaining) + 1))
+            sub, remaining = remaining[:take], remaining[take:]
+            children.append(_rand_container(rng, sub, depth + 1, exotic))
+        else:
+            children.append(_rand_object_node(rng, remaining.pop(0), exotic))
+    if exotic and rng.random() < 0.1:
+        children.append({"type": "flex", "direction": "row", "padding_px": int(rng.integers(0, 9)),
+                         "children": []})  # empty container: padding-only box
+    node["children"] = children
+    return node
+
+
+def flex_case(seed: int) -> dict:
+    """Random Flex tree (depth <= 3) + cutout sizes + canvas size."""
+    rng = np.random.default_rng(40_000 + seed)
+    n = int(rng.integers(1, 9))
+    big = seed % 5 == 0
+    scale = 8 if big else 1
+    sizes = {i + 1: [int(rng.integers(8, 160)) * scale, int(rng.integers(8, 120)) * scale] for i in range(n)}
+    ids = [int(i) for i in rng.permutation(np.arange(1, n + 1))]
+    exotic = seed % 3 == 0
+    if exotic and n > 1 and rng.random() < 0.3:
+        del sizes[ids[0]]  # a node whose cutout is missing
+    root = _rand_container(rng, ids, 1, exotic)
+    W = int(rng.integers(60, 900)) * scale
+    H = int(rng.integers(60, 900)) * scale
+    return dict(name=f"flex_{seed}", sizes=sizes, canvas=[W, H], layout={"root": root})
+
+
+N_FLEX = 240
+
+FLEX_ERROR_NODES = [
+    # (object node fields, exception type name) -- messages are stored by make_golden.py
+    {"padding_px": -1}, {"padding_px": "4"}, {"padding_px": {"left": 1, "front": 2}},
+    {"padding_px": {"left": 1.5}}, {"padding_px": {"top": -3}},
+    {"pin": "center"}, {"pin": {"diagonal": "start"}}, {"pin": {"horizontal": "middle"}},
+    {"offset_px": [1, 2]}, {"offset_px": {"z": 1}}, {"offset_px": {"x": 1.5}},
+    {"stick_to": "left"}, {"stick_to": {"edges": []}}, {"stick_to": {"edges": "left"}},
+    {"stick_to": {"edges": [1]}}, {"stick_to": {"edges": ["centre"]}},
+    {"stick_to": {"edges": ["left", "LEFT"]}}, {"stick_to": {"edges": ["left", "right"]}},
+    {"stick_to": {"edges": ["top", "bottom"]}}, {"stick_to": {"edges": ["top"], "margin_px": 1.5}},
+    {"stick_to": {"edges": ["top"], "margin_px": -1}}, {"stick_to": {"edges": ["top"], "side": 1}},
+]
+
+# Nested-layout known answers on the squarespace bundle
+SQUARESPACE_SIZES = {1: [230, 62], 2: [357, 207], 3: [257, 137], 4: [131, 32]}
+
+
+# ----------------------------------------------------------------------------- canvas sizes
+CANVAS_ORIGINALS = [(970, 250), (1920, 1080), (3840, 2160), (1, 1), (13, 7), (640, 480), (1001, 999)]
+CANVAS_RATIOS = ["1:1", "9:16", "16:9", "21:9", "4:3", "3:4", "2.5:1", "1:3"]

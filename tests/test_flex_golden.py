@@ -1,0 +1,102 @@
+"""Host-side Flex-DSL placement (image_transformation_amd.flex) vs boxes captured from the
+reference's _measure_flex_node/_place_flex_container/_clamp_boxes_to_canvas
+(macro_placement_test.py:637-964).  Bar: bit-exact integers, identical placement dicts."""
+import copy
+import json
+import os
+
+import pytest
+
+import cases
+from image_transformation_amd import flex
+from image_transformation_amd.layout_constraints import compute_canvas_size, parse_ratio
+
+
+@pytest.fixture(scope="module")
+def flex_golden(golden_dir):
+    with open(os.path.join(golden_dir, "flex.json"), encoding="utf-8") as f:
+        return json.load(f)
+
+
+def _run(case):
+    sizes = {int(k): tuple(v) for k, v in case["sizes"].items()}
+    placed = []
+    flex.place_container(case["layout"]["root"], (0, 0), tuple(case["canvas"]), sizes, placed, "flex_root")
+    measured = list(flex.measure(case["layout"]["root"], sizes))
+    clamped = copy.deepcopy(placed)
+    flex.clamp_boxes(clamped, tuple(case["canvas"]))
+    return measured, placed, clamped
+
+
+def test_random_trees_match_reference(flex_golden):
+    assert len(flex_golden["cases"]) >= 200
+    for case in flex_golden["cases"]:
+        measured, placed, clamped = _run(case)
+        assert measured == case["measured"], case["name"]
+        assert placed == case["placed"], case["name"]
+        assert clamped == case["clamped"], case["name"]
+
+
+def test_nested_known_answers(flex_golden):
+    kat = {c["name"]: c for c in flex_golden["kat"]}
+    for case in kat.values():
+        _, placed, clamped = _run(case)
+        assert placed == case["placed"] and clamped == case["clamped"], case["name"]
+    boxes = lambda n: [p["box"] for p in kat[n]["clamped"]]  # noqa: E731
+    # SURVEY.md App. A.6
+    assert boxes("column_all") == [[131, 27, 361, 89], [67, 89, 424, 296], [117, 296, 374, 433], [180, 433, 311, 465]]
+    assert boxes("nested") == [[65, 43, 295, 105], [295, 58, 426, 90], [67, 105, 424, 312], [117, 312, 374, 449]]
+    assert boxes("nested_row_opts") == [[61, 43, 291, 105], [298, 73, 429, 105], [67, 112, 424, 319], [117, 319, 374, 456]]
+    assert boxes("root_opts") == [[11, 11, 241, 73], [241, 26, 372, 58], [11, 105, 368, 312], [11, 344, 268, 481]]
+    assert [p["box"] for p in kat["root_row_overflow"]["placed"]][2:] == [[361, 142, 718, 349], [718, 177, 975, 314]]
+    assert boxes("root_row_overflow")[2:] == [[135, 142, 492, 349], [235, 177, 492, 314]]
+    assert boxes("object_padding") == [[65, 38, 295, 100], [295, 53, 426, 85], [77, 110, 434, 317], [117, 317, 374, 454]]
+    assert boxes("object_pin_offset_stick") == boxes("nested")  # pins/offsets/sticks are arithmetic no-ops
+
+
+def test_layout_to_placements_forms(flex_golden):
+    case = flex_golden["kat"][1]
+    sizes = {int(k): tuple(v) for k, v in case["sizes"].items()}
+    assert flex.layout_to_placements(case["layout"], sizes, case["canvas"]) == case["clamped"]
+    pl = [{"object_id": 1, "box": [0, 0, 5, 5]}]
+    assert flex.layout_to_placements(pl, sizes, (9, 9)) == pl
+    assert flex.layout_to_placements({"placements": pl}, sizes, (9, 9)) == pl
+    with pytest.raises(KeyError):
+        flex.layout_to_placements({"error": "planner failed"}, sizes, (9, 9))  # macro_placement_test.py:1495
+
+
+def test_object_field_errors(flex_golden):
+    sizes = {k: tuple(v) for k, v in cases.SQUARESPACE_SIZES.items()}
+    for row in flex_golden["errors"]:
+        node = dict({"object_id": 2}, **row["fields"])
+        layout = {"root": {"type": "flex", "direction": "row", "children": [{"object_id": 1}, node]}}
+        if row["error"] is None:
+            flex.layout_to_placements(layout, sizes, (492, 492))
+            continue
+        with pytest.raises(ValueError) as ei:
+            flex.layout_to_placements(layout, sizes, (492, 492))
+        assert type(ei.value).__name__ == row["error"]
+        assert str(ei.value) == row["message"], row["fields"]
+
+
+def test_canvas_sizes(golden_dir, capsys):
+    with open(os.path.join(golden_dir, "canvas_sizes.json"), encoding="utf-8") as f:
+        g = json.load(f)
+    for r in g["rows"]:
+        assert list(compute_canvas_size(tuple(r["original"]), r["ratio"], quiet=True)) == r["size"], r
+    for e in g["errors"]:
+        if e["error"] is None:
+            compute_canvas_size((100, 100), e["ratio"], quiet=True)
+        else:
+            with pytest.raises(Exception) as ei:
+                compute_canvas_size((100, 100), e["ratio"], quiet=True)
+            assert type(ei.value).__name__ == e["error"], e
+    assert compute_canvas_size((970, 250), "1:1") == (492, 492)
+    assert "Canvas sizing: 970x250" in capsys.readouterr().out  # the reference prints (layout_constraints.py:84)
+
+
+def test_reference_layout_constraints_test_restated():
+    """tests/test_layout_constraints.py:5-13 of the reference."""
+    tw, th = compute_canvas_size((1920, 1080), "9:16", quiet=True)
+    assert abs(tw / th - parse_ratio("9:16")) < 0.02
+    assert abs(tw * th - 1920 * 1080) / (1920 * 1080) < 0.02
