@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- composited Mpixels/s at 4K canvas, 32 objects (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload = "C3"): synthetic 3840x2160 canvas, 32 RGBA cutouts (binary alpha, as
+the reference's bundles), depth-2 row/column Flex-DSL layouts (seed 3).
+One step = one pass of the hot path over one batch: B distinct Flex layouts of the bundle are
+composited onto B canvases by ONE mic_composite_batch call per GPU (table upload + one kernel
+launch).  Timed region: placements + atlas resident on the device -> canvases complete in HBM
+(SURVEY.md section 8d); Flex box maths, atlas upload/broadcast and D2H are outside and are reported
+separately.  Output canvases rotate over > 256 MiB so the Infinity Cache cannot hold them.
+
+N > 1: one process per GPU, variants sharded v -> GPU v mod N, the atlas is broadcast once over
+RCCL before the timed region, no collective on the data path ("scaling": "weak": B per GPU fixed).
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(objs, placements, size, budget_s=10.0, max_reps=50):
+    """The CPU oracle ("port" of the reference's Pillow path, 1 thread) on the same workload:
+    bounded sample of whole-canvas composites of layout 0."""
+    import numpy as np
+    import oracle
+    from image_transformation_amd.synthetic import SOLID_BG
+
+    W, H = size
+    bg = np.empty((H, W, 4), np.uint8)
+    bg[:] = np.asarray(SOLID_BG, np.uint8)
+    oracle.composite(bg, objs, placements)  # warm-up
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < max_reps and (time.perf_counter() - t_all) < budget_s:
+        t0 = time.perf_counter()
+        oracle.composite(bg, objs, placements)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(W * H / med / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": f"{len(times)} reps of one 3840x2160/32-object Flex composite (layout 0), median "
+                      f"{med * 1e3:.1f} ms, oracle/mic_oracle.c single thread, nproc={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=16, help="canvases per step per GPU")
+    ap.add_argument("--alpha", default="binary", choices=["binary", "soft", "opaque"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from image_transformation_amd import _native, flex, synthetic
+    from image_transformation_amd.batch import broadcast_atlas, shard_indices
+    from image_transformation_amd.compositor import CompositeBatch, SolidCanvas, coerce_placements
+
+    B = args.batch
+    size, objs, layouts = synthetic.c3_workload(args.alpha, seed=3, n_layouts=B * world)
+    W, H = size
+
+    # ---- atlas: packed on rank 0, broadcast once over RCCL, resident afterwards ----
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    atlas = broadcast_atlas(objs if rank == 0 or world == 1 else None, src=0)
+    torch.cuda.synchronize()
+    atlas_ms = (time.perf_counter() - t0) * 1e3
+    ctx = atlas.ctx
+
+    # ---- host Flex box maths (layout_json -> boxes), outside the timed region ----
+    mine = shard_indices(len(layouts), rank, world)
+    t0 = time.perf_counter()
+    placements = [flex.layout_to_placements(layouts[v], atlas, size) for v in mine]
+    layout_ms = (time.perf_counter() - t0) * 1e3 / max(len(mine), 1)
+    rows = [coerce_placements(atlas, pl) for pl in placements]
+    plan = CompositeBatch(atlas, [SolidCanvas(size, synthetic.SOLID_BG)] * len(mine), rows)
+
+    # rotating output sets, > 256 MiB in total
+    set_bytes = B * W * H * 4
+    n_sets = max(2, -(-(320 << 20) // set_bytes))
+    out_sets = [plan.alloc_outputs() for _ in range(n_sets)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for k in range(args.warmup):
+        plan.run(out_sets[k % n_sets])
+    torch.cuda.synchronize()
+    stats = ctx.stats()
+
+    # ---- timed region: exactly K steps ----
+    ctx.profile_begin(args.steps)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        plan.run(out_sets[k % n_sets])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    n_prof, comp_ms, _ = ctx.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    px_per_step = B * W * H * world
+    value = px_per_step * args.steps / elapsed / 1e6
+    kernel_ms = comp_ms / max(n_prof, 1)
+    # algorithmic bytes of ONE launch: every canvas written once + every visible cutout pixel read once
+    b_alg = 4 * stats["canvas_pixels"] + 4 * stats["layer_pixels"]
+    achieved = b_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+
+    result = {
+        "metric": "composited Mpixels/s at 4K canvas, 32 objects",
+        "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "C3: 3840x2160 canvas, 32 RGBA cutouts (binary alpha), depth-2 row/column Flex-DSL",
+                   "canvases_per_step_per_gpu": B, "alpha": args.alpha, "parallelism": f"variants sharded v mod {world}",
+                   "background": "solid, synthesised in-kernel", "filter": "identity scale (Flex pipeline)"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "composite_kernel", "kernel_ms": round(kernel_ms, 4),
+                     "algorithmic_bytes_per_launch": b_alg,
+                     "read_frac_of_peak": round(4 * stats["layer_pixels"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                     if kernel_ms > 0 else None},
+        "atlas": {"bytes": atlas.nbytes, "upload_or_broadcast_ms": round(atlas_ms, 3)},
+        "host_layout_ms_per_image": round(layout_ms, 3),
+    }
+
+    if rank == 0 and world == 1 and not args.no_extras:
+        # single-canvas launches (latency view of the same workload)
+        one = CompositeBatch(atlas, [SolidCanvas(size, synthetic.SOLID_BG)], rows[:1])
+        outs1 = [one.alloc_outputs() for _ in range(12)]
+        for k in range(10):
+            one.run(outs1[k % 12])
+        ctx.profile_begin(100)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(100):
+            one.run(outs1[k % 12])
+        torch.cuda.synchronize()
+        e1 = time.perf_counter() - t0
+        n1, c1, _ = ctx.profile_end()
+        s1 = ctx.stats()
+        result["single_canvas"] = {"ms_per_canvas_wall": round(e1 / 100 * 1e3, 4), "kernel_ms": round(c1 / n1, 4),
+                                   "Mpixels_per_s": round(W * H * 100 / e1 / 1e6, 1),
+                                   "roofline_frac": round((4 * s1["canvas_pixels"] + 4 * s1["layer_pixels"]) /
+                                                          (c1 / n1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # placements mode (direct composite() callers): Pillow-exact LANCZOS resample + overlaps
+        psize, pobjs, ppl = synthetic.placements_workload(W, H, 32, 3, "soft")
+        from image_transformation_amd.compositor import Atlas
+        patlas = Atlas(pobjs)
+        pplan = CompositeBatch(patlas, [SolidCanvas(psize, synthetic.SOLID_BG)], [coerce_placements(patlas, ppl)])
+        pout = pplan.alloc_outputs()
+        pplan.run(pout)
+        torch.cuda.synchronize()
+        ctx.profile_begin(10)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            pplan.run(pout)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t0
+        n2, c2, r2 = ctx.profile_end()
+        result["placements_mode_lanczos"] = {"ms_per_canvas_wall": round(e2 / 10 * 1e3, 3),
+                                             "resample_ms": round(r2 / n2, 3), "composite_ms": round(c2 / n2, 4),
+                                             "Mpixels_per_s": round(W * H * 10 / e2 / 1e6, 1)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(objs, placements[0], size)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,179 @@
+"""ctypes binding of libmic.so (include/mic.h).  PyTorch-ROCm is only the buffer handoff:
+device memory is owned by torch uint8 tensors and enters the C ABI as data_ptr().
+
+There is no CPU fallback: if the library is missing or no MI355X is visible, the first use
+raises.  (The CPU oracle under oracle/ is test infrastructure and is never imported here.)
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Dict, Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmic.so")
+
+LANCZOS = 0
+BILINEAR = 1
+
+
+class MicError(RuntimeError):
+    """A libmic call failed (carries the library's status code)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libmic error {code}: {message}")
+        self.code = code
+
+
+class Placement(ctypes.Structure):
+    _fields_ = [("atlas", ctypes.c_int32), ("object_id", ctypes.c_int32), ("box", ctypes.c_int32 * 4)]
+
+
+class Job(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32),
+                ("bg_dev", ctypes.c_void_p), ("bg_rgba", ctypes.c_uint8 * 4),
+                ("n_placements", ctypes.c_int32), ("placements", ctypes.POINTER(Placement)),
+                ("out_dev", ctypes.c_void_p)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint64) for n in
+                ("canvas_pixels", "layer_pixels", "source_pixels", "resampled_layers", "identity_layers",
+                 "skipped_placements", "composite_blocks")]
+
+    def as_dict(self) -> Dict[str, int]:
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+_lib: Optional[ctypes.CDLL] = None
+_lock = threading.Lock()
+
+# name -> (restype, argtypes); every symbol include/mic.h declares
+_P = ctypes.c_void_p
+_I32P = ctypes.POINTER(ctypes.c_int32)
+SYMBOLS = {
+    "mic_last_error": (ctypes.c_char_p, []),
+    "mic_version": (ctypes.c_int, []),
+    "mic_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_P)]),
+    "mic_destroy": (ctypes.c_int, [_P]),
+    "mic_sync": (ctypes.c_int, [_P, _P]),
+    "mic_atlas_create": (ctypes.c_int, [_P, ctypes.c_int, _I32P, _I32P, _I32P, ctypes.POINTER(_P),
+                                        ctypes.POINTER(_P)]),
+    "mic_atlas_blob_size": (ctypes.c_int, [ctypes.c_int, _I32P, _I32P, ctypes.POINTER(ctypes.c_size_t)]),
+    "mic_atlas_blob_layout": (ctypes.c_int, [ctypes.c_int, _I32P, _I32P, _I32P, _P, ctypes.c_size_t,
+                                             ctypes.POINTER(ctypes.c_uint64)]),
+    "mic_atlas_from_device_blob": (ctypes.c_int, [_P, _P, ctypes.c_size_t, _P, ctypes.POINTER(_P)]),
+    "mic_atlas_device_blob": (ctypes.c_int, [_P, ctypes.POINTER(_P), ctypes.POINTER(ctypes.c_size_t)]),
+    "mic_atlas_count": (ctypes.c_int, [_P]),
+    "mic_atlas_lookup": (ctypes.c_int, [_P, ctypes.c_int32, _I32P, _I32P, ctypes.POINTER(_P)]),
+    "mic_atlas_destroy": (ctypes.c_int, [_P]),
+    "mic_composite_batch": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(_P), ctypes.c_int,
+                                           ctypes.POINTER(Job), ctypes.c_int, _P]),
+    "mic_resize": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
+                                  ctypes.c_int, _P]),
+    "mic_median_rgb": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8), _P]),
+    "mic_median_rgb_dev": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P]),
+    "mic_fill_solid": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8), _P]),
+    "mic_thumbnail_size": (ctypes.c_int, [ctypes.c_int32] * 4 + [_I32P, _I32P]),
+    "mic_last_stats": (ctypes.c_int, [_P, ctypes.POINTER(Stats)]),
+    "mic_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
+    "mic_profile_end": (ctypes.c_int, [_P, _P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double),
+                                       ctypes.POINTER(ctypes.c_double)]),
+}
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    """dlopen libmic.so and declare every prototype.  Needs no GPU (symbols only)."""
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -m image_transformation_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the compositor path.")
+    # torch bundles its own libamdhip64 (same SONAME); importing it first makes libmic share that
+    # runtime, so torch streams and tensors are directly usable by the library.
+    import torch  # noqa: F401
+
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return lib
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                _lib = load_library()
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = lib().mic_last_error()
+        raise MicError(rc, msg.decode("utf-8", "replace") if msg else "unknown error")
+
+
+class Context:
+    """One mic_ctx per (process, device); owns the staging ring, scratch arena and tables."""
+
+    def __init__(self, device: int):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("no ROCm device visible to torch: the compositor path needs an MI355X "
+                               "(there is no CPU fallback)")
+        self.device = int(device)
+        self.torch_device = torch.device("cuda", self.device)
+        h = _P()
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream()  # make sure torch has initialised the device first
+            check(lib().mic_create(self.device, ctypes.byref(h)))
+        self.handle = h
+
+    def stream_ptr(self) -> int:
+        import torch
+
+        return int(torch.cuda.current_stream(self.torch_device).cuda_stream)
+
+    def stats(self) -> Dict[str, int]:
+        s = Stats()
+        check(lib().mic_last_stats(self.handle, ctypes.byref(s)))
+        return s.as_dict()
+
+    def profile_begin(self, max_calls: int) -> None:
+        check(lib().mic_profile_begin(self.handle, int(max_calls)))
+
+    def profile_end(self):
+        """-> (calls, composite kernel ms summed, resample passes ms summed); syncs the stream."""
+        n, c, r = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        check(lib().mic_profile_end(self.handle, _P(self.stream_ptr()), ctypes.byref(n), ctypes.byref(c),
+                                    ctypes.byref(r)))
+        return n.value, c.value, r.value
+
+    def sync(self) -> None:
+        check(lib().mic_sync(self.handle, _P(self.stream_ptr())))
+
+
+_contexts: Dict[int, Context] = {}
+
+
+def context(device: Optional[int] = None) -> Context:
+    """The process-wide context of `device` (default: torch's current device)."""
+    import torch
+
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("no ROCm device visible to torch: the compositor path needs an MI355X "
+                               "(there is no CPU fallback)")
+        device = torch.cuda.current_device()
+    device = int(device)
+    with _lock:
+        ctx = _contexts.get(device)
+    if ctx is None:
+        ctx = Context(device)
+        with _lock:
+            ctx = _contexts.setdefault(device, ctx)
+    return ctx

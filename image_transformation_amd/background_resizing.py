@@ -1,0 +1,69 @@
+"""Background synthesis on the GPU behind the reference's background_resizing.py surface.
+
+    fill_solid(background_path, canvas_size) -> RGBA Image         background_resizing.py:25-33
+    _median_color_nontransparent(img_rgba) -> (r, g, b)            background_resizing.py:11-22
+    _load_background_rgba(background_path) -> RGBA Image           background_resizing.py:6-8
+
+The median is an exact histogram median (kernels_median.hip): per channel over the pixels with
+alpha > 0, over all pixels when there are none, truncated like int(np.median(...)).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import numpy as np
+from PIL import Image
+
+from . import _native
+from .compositor import SolidCanvas, _image_to_array, _to_pil, _upload
+
+_P = ctypes.c_void_p
+
+
+def _load_background_rgba(background_path: str) -> Image.Image:
+    return Image.open(background_path).convert("RGBA")
+
+
+def median_color_device(rgba_dev, ctx: Optional[_native.Context] = None) -> Tuple[int, int, int]:
+    """Median colour of a device uint8 (H, W, 4) tensor."""
+    ctx = ctx or _native.context(rgba_dev.device.index)
+    H, W = int(rgba_dev.shape[0]), int(rgba_dev.shape[1])
+    out = (ctypes.c_uint8 * 3)()
+    _native.check(_native.lib().mic_median_rgb(ctx.handle, _P(rgba_dev.data_ptr()), W, H, out,
+                                               _P(ctx.stream_ptr())))
+    return int(out[0]), int(out[1]), int(out[2])
+
+
+def _median_color_nontransparent(img_rgba: Image.Image) -> Tuple[int, int, int]:
+    ctx = _native.context()
+    arr = _image_to_array(img_rgba)
+    if arr.size == 0:
+        raise ValueError("cannot take the median of an empty image")
+    return median_color_device(_upload(arr, ctx), ctx)
+
+
+def solid_canvas(background_path: str, canvas_size: Tuple[int, int]) -> SolidCanvas:
+    """fill_solid() without materialising the pixels: the colour + size, which render() turns
+    into an in-kernel solid background."""
+    color = _median_color_nontransparent(_load_background_rgba(background_path))
+    return SolidCanvas(canvas_size, color + (255,))
+
+
+def fill_solid_device(canvas_size: Tuple[int, int], rgba, device: Optional[int] = None):
+    """Image.new("RGBA", canvas_size, rgba) as a device tensor (H, W, 4)."""
+    import torch
+
+    ctx = _native.context(device)
+    W, H = int(canvas_size[0]), int(canvas_size[1])
+    out = torch.empty((H, W, 4), dtype=torch.uint8, device=ctx.torch_device)
+    col = (ctypes.c_uint8 * 4)(*[int(v) for v in rgba])
+    _native.check(_native.lib().mic_fill_solid(ctx.handle, _P(out.data_ptr()), W, H, col, _P(ctx.stream_ptr())))
+    return out
+
+
+def fill_solid(background_path: str, canvas_size: Tuple[int, int]) -> Image.Image:
+    """Solid RGBA canvas in the median non-transparent colour of background.png
+    (background_resizing.py:25-33)."""
+    sc = solid_canvas(background_path, canvas_size)
+    return _to_pil(fill_solid_device(sc.size, sc.rgba))

@@ -1,0 +1,407 @@
+"""MI355X compositor behind the reference's compositor.py call surface.
+
+    composite(background_img, object_images, placements) -> Image      compositor.py:6-22
+    load_object_images(results_json_path) -> {int id: RGBA Image}      compositor.py:25-35
+    render(layout_json, objects, canvas) -> Image                      (north_star; = place + clamp +
+                                                                        composite, macro_placement_test.py:1495-1511)
+
+plus the device-resident forms a batch caller uses (Atlas, render_batch).  The pixel work --
+Pillow-exact LANCZOS resampling, ordered 8-bit alpha-over, solid background synthesis -- runs in
+the HIP kernels of libmic.so; PIL images are only the handoff type the reference's callers expect
+(they .save() the result, macro_placement_test.py:1513).  Nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+from typing import Any, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple, Union
+
+import numpy as np
+from PIL import Image
+
+from . import _native
+from ._native import LANCZOS, BILINEAR, Placement, Job  # noqa: F401
+from . import flex
+
+_P = ctypes.c_void_p
+_FILTERS = {LANCZOS, BILINEAR}
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def _torch():
+    import torch
+
+    return torch
+
+
+def _image_to_array(img: Image.Image) -> np.ndarray:
+    """RGBA PIL image -> (H, W, 4) uint8 (a copy of the raw bytes; no arithmetic)."""
+    if img.mode != "RGBA":
+        raise ValueError("image has wrong mode")  # what Pillow's core.alpha_composite raises
+    return np.asarray(img, dtype=np.uint8)
+
+
+def _upload(arr: np.ndarray, ctx: _native.Context):
+    torch = _torch()
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    return t.to(ctx.torch_device, non_blocking=False)
+
+
+def _to_pil(canvas_dev) -> Image.Image:
+    arr = canvas_dev.cpu().numpy()
+    return Image.frombuffer("RGBA", (arr.shape[1], arr.shape[0]), arr.tobytes(), "raw", "RGBA", 0, 1)
+
+
+class _Entry:
+    """What flex needs from an object: `.size` (as a PIL image has)."""
+    __slots__ = ("size",)
+
+    def __init__(self, size):
+        self.size = size
+
+
+def pack_blob(objects: Mapping[int, Any], pin: bool = False):
+    """{id: RGBA image/array} -> host uint8 tensor in libmic's atlas blob layout (header, table,
+    256-byte aligned pixels).  Needs no GPU; this is what rank 0 broadcasts to the other GPUs."""
+    lib = _native.lib()
+    ids: List[int] = []
+    arrs: List[np.ndarray] = []
+    for oid, im in objects.items():
+        arr = _image_to_array(im) if isinstance(im, Image.Image) else np.ascontiguousarray(im, np.uint8)
+        if arr.ndim != 3 or arr.shape[2] != 4:
+            raise ValueError("image has wrong mode")
+        ids.append(int(oid))
+        arrs.append(arr)
+    n = len(ids)
+    ids_a = np.asarray(ids, np.int32)
+    ws = np.asarray([a.shape[1] for a in arrs], np.int32)
+    hs = np.asarray([a.shape[0] for a in arrs], np.int32)
+    nbytes = ctypes.c_size_t()
+    _native.check(lib.mic_atlas_blob_size(n, _i32p(ws), _i32p(hs), ctypes.byref(nbytes)))
+    torch = _torch()
+    host = torch.zeros(nbytes.value, dtype=torch.uint8)
+    if pin and torch.cuda.is_available():
+        host = host.pin_memory()
+    host_np = host.numpy()
+    offs = np.zeros(max(n, 1), np.uint64)
+    _native.check(lib.mic_atlas_blob_layout(n, _i32p(ids_a), _i32p(ws), _i32p(hs), _P(host_np.ctypes.data),
+                                            nbytes.value, offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
+    for a, off in zip(arrs, offs):
+        host_np[int(off):int(off) + a.size] = a.reshape(-1)
+    return host
+
+
+def parse_blob_header(raw: np.ndarray) -> Dict[int, Tuple[int, int]]:
+    """Blob bytes (at least header + table) -> {id: (w, h)}; first occurrence of an id wins."""
+    raw = np.ascontiguousarray(raw, np.uint8)
+    head = np.frombuffer(raw[:32].tobytes(), np.uint32)
+    if head[0] != 0x4143494D:
+        raise ValueError("not an atlas blob")
+    n = int(head[2])
+    tab = np.frombuffer(raw[32:32 + 32 * n].tobytes(), np.int32).reshape(n, 8) if n else np.zeros((0, 8), np.int32)
+    sizes: Dict[int, Tuple[int, int]] = {}
+    for row in tab:
+        sizes.setdefault(int(row[0]), (int(row[1]), int(row[2])))
+    return sizes
+
+
+class Atlas(Mapping):
+    """Device-resident packed cutouts: the on-GPU form of load_object_images()'s dict.
+
+    Uploaded once per bundle and reused by every composite / refine iteration / variant
+    (the reference re-decodes the PNGs each iteration, macro_placement_test.py:1493,1679).
+    Behaves as a read-only mapping id -> entry with `.size`, which is all the layout code
+    needs (macro_placement_test.py:645,708 only read img.size).
+    """
+
+    def __init__(self, objects: Mapping[int, Any], device: Optional[int] = None):
+        self.ctx = _native.context(device)
+        host = pack_blob(objects, pin=True)
+        self._init_from_blob(host.to(self.ctx.torch_device), header=host.numpy())
+
+    def _init_from_blob(self, blob, header: Optional[np.ndarray] = None):
+        self.blob = blob  # torch uint8 tensor on the device; owns the memory
+        if header is None:
+            n = int(np.frombuffer(blob[:32].cpu().numpy().tobytes(), np.uint32)[2])
+            header = blob[:32 + 32 * n].cpu().numpy()
+        self._sizes = parse_blob_header(header)
+        h = _P()
+        _native.check(_native.lib().mic_atlas_from_device_blob(
+            self.ctx.handle, _P(blob.data_ptr()), blob.numel(), _P(header.ctypes.data), ctypes.byref(h)))
+        self.handle = h
+
+    @classmethod
+    def from_blob(cls, blob, device: Optional[int] = None) -> "Atlas":
+        """Wrap a device blob (e.g. the result of a torch.distributed broadcast)."""
+        self = cls.__new__(cls)
+        self.ctx = _native.context(device if device is not None else blob.device.index)
+        self._init_from_blob(blob)
+        return self
+
+    # Mapping protocol (id -> entry with .size)
+    def __getitem__(self, oid):
+        return _Entry(self._sizes[oid])
+
+    def __iter__(self):
+        return iter(self._sizes)
+
+    def __len__(self):
+        return len(self._sizes)
+
+    @property
+    def nbytes(self) -> int:
+        return int(self.blob.numel())
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            try:
+                _native.lib().mic_atlas_destroy(h)
+            except Exception:
+                pass
+            self.handle = None
+
+
+class ObjectImages(dict):
+    """dict {id: RGBA Image} as load_object_images returns it, plus a lazily uploaded Atlas that
+    is dropped whenever the dict is modified."""
+
+    _atlas: Optional[Atlas] = None
+
+    def atlas(self, device: Optional[int] = None) -> Atlas:
+        if self._atlas is None or (device is not None and self._atlas.ctx.device != device):
+            self._atlas = Atlas(self, device)
+        return self._atlas
+
+    def _touch(self):
+        self._atlas = None
+
+    def __setitem__(self, k, v):
+        self._touch()
+        super().__setitem__(k, v)
+
+    def __delitem__(self, k):
+        self._touch()
+        super().__delitem__(k)
+
+    def update(self, *a, **kw):
+        self._touch()
+        super().update(*a, **kw)
+
+    def pop(self, *a):
+        self._touch()
+        return super().pop(*a)
+
+    def clear(self):
+        self._touch()
+        super().clear()
+
+
+def _i32p(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+
+
+def _as_atlas(objects, device: Optional[int] = None) -> Atlas:
+    if isinstance(objects, Atlas):
+        return objects
+    if isinstance(objects, ObjectImages):
+        return objects.atlas(device)
+    return Atlas(objects, device)
+
+
+def load_object_images(results_json_path: str) -> Dict[int, Image.Image]:
+    """results.json -> {object_id: RGBA Image} (compositor.py:25-35).  PNG decode stays on the
+    host; the returned dict uploads itself to the GPU once, on first use."""
+    with open(results_json_path, "r", encoding="utf-8") as f:
+        items = json.load(f)
+    base = os.path.dirname(results_json_path)
+    out = ObjectImages()
+    for it in items:
+        out[int(it["object_id"])] = Image.open(os.path.join(base, it["filename"])).convert("RGBA")
+    return out
+
+
+def coerce_placements(known_ids, placements: Iterable[Mapping]) -> List[Tuple[int, int, int, int, int]]:
+    """The Python-level semantics of compositor.py:12-16: object_id through int() unless already
+    an int, unknown ids skipped, box = exactly four values each through int() (truncation)."""
+    rows = []
+    for p in placements:
+        oid = p["object_id"]
+        if not isinstance(oid, int):
+            oid = int(oid)
+        if oid not in known_ids:
+            continue
+        x1, y1, x2, y2 = [int(v) for v in p["box"]]
+        rows.append((oid, x1, y1, x2, y2))
+    return rows
+
+
+_I32_MIN, _I32_MAX = -(2 ** 31), 2 ** 31 - 1
+
+
+def _fill_placements(rows: Sequence[Tuple[int, int, int, int, int]], atlas_index: int = 0):
+    arr = (Placement * max(len(rows), 1))()
+    for i, (oid, x1, y1, x2, y2) in enumerate(rows):
+        if not (_I32_MIN <= x1 <= _I32_MAX and _I32_MIN <= y1 <= _I32_MAX and
+                _I32_MIN <= x2 <= _I32_MAX and _I32_MIN <= y2 <= _I32_MAX and _I32_MIN <= oid <= _I32_MAX):
+            raise OverflowError("placement coordinates do not fit 32 bits")
+        p = arr[i]
+        p.atlas = atlas_index
+        p.object_id = oid
+        p.box[0], p.box[1], p.box[2], p.box[3] = x1, y1, x2, y2
+    return arr
+
+
+class SolidCanvas:
+    """A canvas that is one colour: what fill_solid() produces (background_resizing.py:25-33).
+    Passing it to render() lets the kernel synthesise the background instead of reading it."""
+
+    def __init__(self, size: Tuple[int, int], rgba: Sequence[int]):
+        self.size = (int(size[0]), int(size[1]))
+        rgba = tuple(int(v) for v in rgba)
+        if len(rgba) == 3:
+            rgba = rgba + (255,)
+        if len(rgba) != 4 or any(not 0 <= v <= 255 for v in rgba):
+            raise ValueError("colour must be 3 or 4 values in 0..255")
+        self.rgba = rgba
+
+    def to_image(self) -> Image.Image:
+        return Image.new("RGBA", self.size, self.rgba)
+
+
+def _make_job(size, bg_dev_ptr, bg_rgba, placement_arr, n_place, out_ptr) -> Job:
+    j = Job()
+    j.width, j.height = size
+    j.bg_dev = bg_dev_ptr
+    for k in range(4):
+        j.bg_rgba[k] = bg_rgba[k]
+    j.n_placements = n_place
+    j.placements = ctypes.cast(placement_arr, ctypes.POINTER(Placement))
+    j.out_dev = out_ptr
+    return j
+
+
+class CompositeBatch:
+    """A batch of composite jobs marshalled once: canvases + coerced placement rows as the C ABI's
+    mic_job / mic_placement arrays.  run() only swaps the output pointers and makes ONE
+    mic_composite_batch call (one launch for the whole batch), so a caller that re-composites the
+    same variants (or times the path) pays no per-placement Python cost.
+
+    canvases[i] is a SolidCanvas or a contiguous torch uint8 (H, W, 4) tensor on the atlas'
+    device; placement_rows[i] = [(object_id, x1, y1, x2, y2), ...] already coerced."""
+
+    def __init__(self, atlas: Atlas, canvases: Sequence[Union[SolidCanvas, Any]],
+                 placement_rows: Sequence[Sequence[Tuple[int, int, int, int, int]]], filter: int = LANCZOS):
+        if filter not in _FILTERS:
+            raise ValueError(f"unknown filter {filter}")
+        torch = _torch()
+        self.atlas = atlas
+        self.ctx = atlas.ctx
+        self.filter = filter
+        self.n = len(canvases)
+        if len(placement_rows) != self.n:
+            raise ValueError("one placement list per canvas")
+        self.jobs = (Job * max(self.n, 1))()
+        self.sizes: List[Tuple[int, int]] = []
+        self._keep: List[Any] = []
+        for i, (cv, rows) in enumerate(zip(canvases, placement_rows)):
+            if isinstance(cv, SolidCanvas):
+                W, H = cv.size
+                bg_ptr, rgba = None, cv.rgba
+            else:
+                if cv.dtype != torch.uint8 or cv.dim() != 3 or cv.shape[2] != 4 or not cv.is_contiguous():
+                    raise ValueError("device canvas must be a contiguous uint8 (H, W, 4) tensor")
+                if cv.device != self.ctx.torch_device:
+                    raise ValueError("canvas lives on another device than the atlas")
+                H, W = int(cv.shape[0]), int(cv.shape[1])
+                bg_ptr, rgba = cv.data_ptr(), (0, 0, 0, 0)
+                self._keep.append(cv)
+            parr = _fill_placements(rows)
+            self._keep.append(parr)
+            self.jobs[i] = _make_job((W, H), bg_ptr, rgba, parr, len(rows), None)
+            self.sizes.append((W, H))
+        self._atl = (_P * 1)(atlas.handle)
+
+    def alloc_outputs(self):
+        torch = _torch()
+        return [torch.empty((H, W, 4), dtype=torch.uint8, device=self.ctx.torch_device) for (W, H) in self.sizes]
+
+    def run(self, outs: Optional[Sequence[Any]] = None):
+        """Enqueue the batch on torch's current stream (not synchronised); returns the outputs."""
+        torch = _torch()
+        if outs is None:
+            outs = self.alloc_outputs()
+        if len(outs) != self.n:
+            raise ValueError("one output canvas per job")
+        for i, out in enumerate(outs):
+            W, H = self.sizes[i]
+            if tuple(out.shape) != (H, W, 4) or out.dtype != torch.uint8 or not out.is_contiguous():
+                raise ValueError("output canvas has the wrong shape/dtype")
+            self.jobs[i].out_dev = out.data_ptr()
+        _native.check(_native.lib().mic_composite_batch(self.ctx.handle, 1, self._atl, self.n, self.jobs,
+                                                        self.filter, _P(self.ctx.stream_ptr())))
+        return list(outs)
+
+
+def composite_device(atlas: Atlas, canvases: Sequence[Union[SolidCanvas, Any]],
+                     placement_rows: Sequence[Sequence[Tuple[int, int, int, int, int]]],
+                     outs: Optional[Sequence[Any]] = None, filter: int = LANCZOS):
+    """Batch composite, everything device-resident (see CompositeBatch).  Returns the list of output
+    canvases (torch uint8 (H, W, 4)); work is enqueued on torch's current stream."""
+    return CompositeBatch(atlas, canvases, placement_rows, filter).run(outs)
+
+
+def composite(background_img: Image.Image, object_images: Mapping[int, Image.Image],
+              placements: List[Dict], *, filter: int = LANCZOS) -> Image.Image:
+    """Drop-in for the reference's composite() (compositor.py:6-22).
+
+    placements: list of {object_id, box: [x1, y1, x2, y2]}; extra keys are ignored.  Painter's
+    order = list order; unknown ids are skipped; the background image is not modified."""
+    rows = coerce_placements(object_images, placements)
+    if not rows:
+        return background_img.copy()  # compositor.py:11 with an empty loop
+    bg = _image_to_array(background_img)
+    atlas = _as_atlas(object_images)
+    bg_dev = _upload(bg, atlas.ctx)
+    out = composite_device(atlas, [bg_dev], [rows], filter=filter)[0]
+    return _to_pil(out)
+
+
+def _canvas_size(canvas) -> Tuple[int, int]:
+    if isinstance(canvas, (SolidCanvas, Image.Image)):
+        return canvas.size
+    return int(canvas.shape[1]), int(canvas.shape[0])  # tensor (H, W, 4)
+
+
+def render(layout_json: Any, objects: Mapping[int, Any], canvas: Any, *, filter: int = LANCZOS,
+           as_tensor: bool = False):
+    """render(layout_json, objects, canvas): Flex-DSL layout -> boxes -> composite.
+
+    Equals composite(canvas, objects, clamp(place(layout_json))) of the reference exactly
+    (macro_placement_test.py:1495-1498 + :1511).  layout_json: {"root": flex tree} (placed from
+    (0,0) over the whole canvas, then clamped), or {"placements": [...]}/a list (used as-is).
+    objects: the dict from load_object_images, any {id: RGBA Image}, or an Atlas.
+    canvas: an RGBA PIL image, a SolidCanvas, or a device uint8 (H, W, 4) tensor."""
+    atlas = _as_atlas(objects)
+    size = _canvas_size(canvas)
+    placements = flex.layout_to_placements(layout_json, objects if not isinstance(objects, Atlas) else atlas, size)
+    rows = coerce_placements(atlas, placements)
+    if isinstance(canvas, Image.Image):
+        if not rows and not as_tensor:
+            return canvas.copy()
+        canvas = _upload(_image_to_array(canvas), atlas.ctx)
+    out = composite_device(atlas, [canvas], [rows], filter=filter)[0]
+    return out if as_tensor else _to_pil(out)
+
+
+def render_batch(layouts: Sequence[Any], objects: Mapping[int, Any], canvases: Sequence[Any], *,
+                 filter: int = LANCZOS, outs: Optional[Sequence[Any]] = None):
+    """One launch for a batch of variants of one bundle (BASELINE.json configs[3]): layouts[i] onto
+    canvases[i].  Returns device tensors; nothing is copied to the host."""
+    atlas = _as_atlas(objects)
+    rows = []
+    for layout, cv in zip(layouts, canvases):
+        pl = flex.layout_to_placements(layout, atlas, _canvas_size(cv))
+        rows.append(coerce_placements(atlas, pl))
+    return composite_device(atlas, list(canvases), rows, outs=outs, filter=filter)

@@ -1,0 +1,755 @@
+// Host runtime + C ABI of libmic.so (see include/mic.h for the contract).
+//
+// What lives here: the context (pinned/params staging ring, scratch arena for resampled layers,
+// device-resident coefficient tables), the atlas (packed cutouts), and the resolution of
+// placements into device layer tables for the kernels.  No pixel arithmetic runs on the host.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/mic.h"
+#include "mic_internal.h"
+#include "resample_coeffs.h"
+
+using namespace mic;
+
+// ------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? MIC_ERR_NOMEM : MIC_ERR_HIP, "%s: %s",   \
+                        #expr, hipGetErrorString(e_));                                       \
+    } while (0)
+
+extern "C" const char *mic_last_error(void) { return g_err; }
+extern "C" int mic_version(void) { return (1 << 16) | 0; }
+
+// ------------------------------------------------------------------------------------ blob layout
+namespace {
+
+constexpr uint32_t kBlobMagic = 0x4143494du;  // "MICA"
+constexpr uint32_t kBlobVersion = 1;
+constexpr size_t kPixelAlign = 256;
+constexpr int64_t kMaxDim = 65535;
+
+struct BlobHeader {
+    uint32_t magic, version, n, reserved;
+    uint64_t total_bytes, pixels_offset;
+};
+struct BlobEntry {
+    int32_t id, w, h, pad;
+    uint64_t offset, reserved;
+};
+static_assert(sizeof(BlobHeader) == 32 && sizeof(BlobEntry) == 32, "blob layout");
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline size_t header_bytes(int n) { return sizeof(BlobHeader) + sizeof(BlobEntry) * (size_t)n; }
+
+int blob_layout(int n, const int32_t *ids, const int32_t *w, const int32_t *h,
+                std::vector<BlobEntry> *entries, size_t *total) {
+    if (n < 0) return fail(MIC_ERR_INVALID, "atlas: negative object count");
+    size_t off = align_up(header_bytes(n), kPixelAlign);
+    const size_t pixels_offset = off;
+    if (entries) entries->clear();
+    for (int i = 0; i < n; ++i) {
+        if (w[i] <= 0 || h[i] <= 0 || w[i] > kMaxDim || h[i] > kMaxDim)
+            return fail(MIC_ERR_INVALID, "atlas: object %d has invalid size %dx%d", i, w[i], h[i]);
+        if (entries) entries->push_back(BlobEntry{ids ? ids[i] : i, w[i], h[i], 0, off, 0});
+        off = align_up(off + (size_t)w[i] * h[i] * 4, kPixelAlign);
+    }
+    (void)pixels_offset;
+    *total = off;
+    return MIC_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ context
+namespace {
+constexpr int kSlots = 8;
+
+struct Slot {
+    void *host = nullptr;
+    void *dev = nullptr;
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+};
+
+struct CoefKey {
+    int in, out, filter, transposed;
+    bool operator<(const CoefKey &o) const {
+        return std::tie(in, out, filter, transposed) < std::tie(o.in, o.out, o.filter, o.transposed);
+    }
+};
+struct CoefEntry {
+    int ksize = 0;
+    int32_t *bounds = nullptr;  // device
+    int32_t *coeffs = nullptr;  // device
+};
+}  // namespace
+
+struct mic_ctx {
+    int device = 0;
+    Slot slots[kSlots];
+    int next_slot = 0;
+    void *arena = nullptr;
+    size_t arena_cap = 0;
+    std::map<CoefKey, CoefEntry> coefs;
+    uint32_t *median_scratch = nullptr;  // device: histogram words + 1 result word
+    uint32_t *median_host = nullptr;     // pinned
+    hipStream_t last_stream = nullptr;
+    mic_stats stats{};
+    uint64_t next_atlas_uid = 1;
+    // optional event brackets around the kernels (mic_profile_begin/end)
+    std::vector<hipEvent_t> prof_events;  // 3 per call: before resample, before composite, after
+    int prof_calls = 0, prof_max = 0;
+    bool profiling = false;
+};
+
+struct mic_atlas {
+    mic_ctx *ctx = nullptr;
+    void *blob = nullptr;
+    size_t bytes = 0;
+    bool owns = false;
+    uint64_t uid = 0;
+    std::vector<BlobEntry> entries;
+    std::unordered_map<int32_t, int> index;
+};
+
+static int ctx_enter(mic_ctx *ctx) {
+    if (!ctx) return fail(MIC_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return MIC_OK;
+}
+
+extern "C" int mic_create(int device, mic_ctx **out) {
+    if (!out) return fail(MIC_ERR_INVALID, "mic_create: null out");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(MIC_ERR_NODEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= count)
+        return fail(MIC_ERR_INVALID, "device %d out of range (have %d)", device, count);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MIC_ERR_NODEVICE, "device %d is %s; libmic is built for gfx950 (MI355X) only", device,
+                    prop.gcnArchName);
+    mic_ctx *ctx = new (std::nothrow) mic_ctx();
+    if (!ctx) return fail(MIC_ERR_NOMEM, "out of host memory");
+    ctx->device = device;
+    for (auto &s : ctx->slots) {
+        e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
+        if (e != hipSuccess) {
+            mic_destroy(ctx);
+            return fail(MIC_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+        }
+    }
+    e = hipMalloc(&ctx->median_scratch, (kMedianScratchWords + 8) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->median_host), 64, 0);
+    if (e != hipSuccess) {
+        mic_destroy(ctx);
+        return fail(MIC_ERR_HIP, "context allocation: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return MIC_OK;
+}
+
+extern "C" int mic_destroy(mic_ctx *ctx) {
+    if (!ctx) return MIC_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto &s : ctx->slots) {
+        if (s.host) (void)hipHostFree(s.host);
+        if (s.dev) (void)hipFree(s.dev);
+        if (s.ev) (void)hipEventDestroy(s.ev);
+    }
+    for (auto &kv : ctx->coefs) {
+        if (kv.second.bounds) (void)hipFree(kv.second.bounds);
+        if (kv.second.coeffs) (void)hipFree(kv.second.coeffs);
+    }
+    for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->median_scratch) (void)hipFree(ctx->median_scratch);
+    if (ctx->median_host) (void)hipHostFree(ctx->median_host);
+    delete ctx;
+    return MIC_OK;
+}
+
+extern "C" int mic_sync(mic_ctx *ctx, void *stream) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return MIC_OK;
+}
+
+// A context is driven from one stream at a time; if the caller switches streams, order the new
+// one after the old one's work (the arena and the staging ring are shared).
+static int adopt_stream(mic_ctx *ctx, hipStream_t stream) {
+    if (ctx->last_stream != stream) {
+        HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+        ctx->last_stream = stream;
+    }
+    return MIC_OK;
+}
+
+static int acquire_slot(mic_ctx *ctx, size_t bytes, Slot **out) {
+    Slot &s = ctx->slots[ctx->next_slot];
+    ctx->next_slot = (ctx->next_slot + 1) % kSlots;
+    if (s.pending) {  // the copy out of this slot's pinned buffer must have finished
+        HIP_TRY(hipEventSynchronize(s.ev));
+        s.pending = false;
+    }
+    if (s.cap < bytes) {
+        // The device half may still be read by an earlier launch of the same stream.
+        HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+        if (s.host) HIP_TRY(hipHostFree(s.host));
+        if (s.dev) HIP_TRY(hipFree(s.dev));
+        s.host = s.dev = nullptr;
+        s.cap = 0;
+        const size_t cap = align_up(std::max(bytes, (size_t)64 << 10), 4096);
+        HIP_TRY(hipHostMalloc(&s.host, cap, 0));
+        HIP_TRY(hipMalloc(&s.dev, cap));
+        s.cap = cap;
+    }
+    *out = &s;
+    return MIC_OK;
+}
+
+static int ensure_arena(mic_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->arena_cap) return MIC_OK;
+    HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+    if (ctx->arena) HIP_TRY(hipFree(ctx->arena));
+    ctx->arena = nullptr;
+    ctx->arena_cap = 0;
+    const size_t cap = align_up(std::max(bytes + bytes / 4, (size_t)16 << 20), (size_t)1 << 20);
+    HIP_TRY(hipMalloc(&ctx->arena, cap));
+    ctx->arena_cap = cap;
+    return MIC_OK;
+}
+
+static int get_coefs(mic_ctx *ctx, int in, int out, int filter, bool transposed, CoefEntry *res) {
+    const CoefKey key{in, out, filter, transposed ? 1 : 0};
+    auto it = ctx->coefs.find(key);
+    if (it != ctx->coefs.end()) {
+        *res = it->second;
+        return MIC_OK;
+    }
+    AxisTable t = build_axis_table(in, out, filter);
+    CoefEntry e;
+    e.ksize = t.ksize;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e.bounds), t.bounds.size() * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e.coeffs), t.coeffs.size() * sizeof(int32_t)));
+    // Pageable source: the runtime stages it before returning, the vectors may die afterwards.
+    HIP_TRY(hipMemcpy(e.bounds, t.bounds.data(), t.bounds.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (transposed) {
+        std::vector<int32_t> tr = transpose_coeffs(t);
+        HIP_TRY(hipMemcpy(e.coeffs, tr.data(), tr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(hipMemcpy(e.coeffs, t.coeffs.data(), t.coeffs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    ctx->coefs[key] = e;
+    *res = e;
+    return MIC_OK;
+}
+
+// ------------------------------------------------------------------------------------ atlas
+extern "C" int mic_atlas_blob_size(int n, const int32_t *widths, const int32_t *heights, size_t *bytes) {
+    if (!bytes || (n > 0 && (!widths || !heights))) return fail(MIC_ERR_INVALID, "mic_atlas_blob_size: null argument");
+    return blob_layout(n, nullptr, widths, heights, nullptr, bytes);
+}
+
+extern "C" int mic_atlas_blob_layout(int n, const int32_t *ids, const int32_t *widths, const int32_t *heights,
+                                     void *blob_host, size_t bytes, uint64_t *pixel_offsets) {
+    if (!blob_host || (n > 0 && (!ids || !widths || !heights || !pixel_offsets)))
+        return fail(MIC_ERR_INVALID, "mic_atlas_blob_layout: null argument");
+    std::vector<BlobEntry> entries;
+    size_t total = 0;
+    if (int rc = blob_layout(n, ids, widths, heights, &entries, &total)) return rc;
+    if (bytes < header_bytes(n)) return fail(MIC_ERR_INVALID, "mic_atlas_blob_layout: buffer too small");
+    BlobHeader h{kBlobMagic, kBlobVersion, (uint32_t)n, 0, total, align_up(header_bytes(n), kPixelAlign)};
+    memcpy(blob_host, &h, sizeof h);
+    if (n) memcpy(static_cast<char *>(blob_host) + sizeof h, entries.data(), sizeof(BlobEntry) * n);
+    for (int i = 0; i < n; ++i) pixel_offsets[i] = entries[i].offset;
+    return MIC_OK;
+}
+
+static int atlas_finish(mic_atlas *a) {
+    for (size_t i = 0; i < a->entries.size(); ++i) {
+        // first occurrence wins for duplicate ids, like successive dict writes would not: the Python
+        // binding never passes duplicates (dict keys), so this is only a defined behaviour for C callers
+        a->index.emplace(a->entries[i].id, (int)i);
+    }
+    a->uid = a->ctx->next_atlas_uid++;
+    return MIC_OK;
+}
+
+extern "C" int mic_atlas_create(mic_ctx *ctx, int n, const int32_t *ids, const int32_t *widths,
+                                const int32_t *heights, const uint8_t *const *rgba_host, mic_atlas **out) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    if (!out || (n > 0 && (!ids || !widths || !heights || !rgba_host)))
+        return fail(MIC_ERR_INVALID, "mic_atlas_create: null argument");
+    *out = nullptr;
+    std::vector<BlobEntry> entries;
+    size_t total = 0;
+    if (int rc = blob_layout(n, ids, widths, heights, &entries, &total)) return rc;
+    std::vector<uint8_t> host(total, 0);
+    std::vector<uint64_t> offs((size_t)std::max(n, 1));
+    if (int rc = mic_atlas_blob_layout(n, ids, widths, heights, host.data(), total, offs.data())) return rc;
+    for (int i = 0; i < n; ++i) {
+        if (!rgba_host[i]) return fail(MIC_ERR_INVALID, "mic_atlas_create: object %d has no pixels", i);
+        memcpy(host.data() + offs[i], rgba_host[i], (size_t)widths[i] * heights[i] * 4);
+    }
+    mic_atlas *a = new (std::nothrow) mic_atlas();
+    if (!a) return fail(MIC_ERR_NOMEM, "out of host memory");
+    a->ctx = ctx;
+    a->bytes = total;
+    a->owns = true;
+    hipError_t e = hipMalloc(&a->blob, total);
+    if (e == hipSuccess) e = hipMemcpy(a->blob, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (a->blob) (void)hipFree(a->blob);
+        delete a;
+        return fail(e == hipErrorOutOfMemory ? MIC_ERR_NOMEM : MIC_ERR_HIP, "atlas upload: %s", hipGetErrorString(e));
+    }
+    a->entries = std::move(entries);
+    atlas_finish(a);
+    *out = a;
+    return MIC_OK;
+}
+
+extern "C" int mic_atlas_from_device_blob(mic_ctx *ctx, const void *blob_dev, size_t bytes,
+                                          const void *header_host, mic_atlas **out) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    if (!blob_dev || !out) return fail(MIC_ERR_INVALID, "mic_atlas_from_device_blob: null argument");
+    *out = nullptr;
+    if (bytes < sizeof(BlobHeader)) return fail(MIC_ERR_FORMAT, "atlas blob shorter than its header");
+    BlobHeader h;
+    if (header_host) memcpy(&h, header_host, sizeof h);
+    else HIP_TRY(hipMemcpy(&h, blob_dev, sizeof h, hipMemcpyDeviceToHost));
+    if (h.magic != kBlobMagic || h.version != kBlobVersion)
+        return fail(MIC_ERR_FORMAT, "atlas blob: bad magic/version %08x/%u", h.magic, h.version);
+    if (h.total_bytes > bytes || header_bytes((int)h.n) > bytes)
+        return fail(MIC_ERR_FORMAT, "atlas blob: declared %llu bytes, buffer has %zu",
+                    (unsigned long long)h.total_bytes, bytes);
+    std::vector<BlobEntry> entries(h.n);
+    if (h.n) {
+        if (header_host) memcpy(entries.data(), static_cast<const char *>(header_host) + sizeof h, sizeof(BlobEntry) * h.n);
+        else HIP_TRY(hipMemcpy(entries.data(), static_cast<const char *>(blob_dev) + sizeof h,
+                               sizeof(BlobEntry) * h.n, hipMemcpyDeviceToHost));
+    }
+    for (const BlobEntry &e : entries) {
+        if (e.w <= 0 || e.h <= 0 || e.w > kMaxDim || e.h > kMaxDim || e.offset % 4 != 0 ||
+            e.offset + (uint64_t)e.w * e.h * 4 > h.total_bytes)
+            return fail(MIC_ERR_FORMAT, "atlas blob: entry for id %d is out of bounds", e.id);
+    }
+    mic_atlas *a = new (std::nothrow) mic_atlas();
+    if (!a) return fail(MIC_ERR_NOMEM, "out of host memory");
+    a->ctx = ctx;
+    a->blob = const_cast<void *>(blob_dev);
+    a->bytes = bytes;
+    a->owns = false;
+    a->entries = std::move(entries);
+    atlas_finish(a);
+    *out = a;
+    return MIC_OK;
+}
+
+extern "C" int mic_atlas_device_blob(const mic_atlas *atlas, const void **blob_dev, size_t *bytes) {
+    if (!atlas || !blob_dev || !bytes) return fail(MIC_ERR_INVALID, "mic_atlas_device_blob: null argument");
+    *blob_dev = atlas->blob;
+    *bytes = atlas->bytes;
+    return MIC_OK;
+}
+
+extern "C" int mic_atlas_count(const mic_atlas *atlas) { return atlas ? (int)atlas->entries.size() : 0; }
+
+extern "C" int mic_atlas_lookup(const mic_atlas *atlas, int32_t id, int32_t *width, int32_t *height,
+                                const void **rgba_dev) {
+    if (!atlas) return fail(MIC_ERR_INVALID, "mic_atlas_lookup: null atlas");
+    auto it = atlas->index.find(id);
+    if (it == atlas->index.end()) return fail(MIC_ERR_INVALID, "object id %d is not in the atlas", id);
+    const BlobEntry &e = atlas->entries[it->second];
+    if (width) *width = e.w;
+    if (height) *height = e.h;
+    if (rgba_dev) *rgba_dev = static_cast<const char *>(atlas->blob) + e.offset;
+    return MIC_OK;
+}
+
+extern "C" int mic_atlas_destroy(mic_atlas *atlas) {
+    if (!atlas) return MIC_OK;
+    if (atlas->owns && atlas->blob) {
+        (void)hipSetDevice(atlas->ctx->device);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(atlas->blob);
+    }
+    delete atlas;
+    return MIC_OK;
+}
+
+// ------------------------------------------------------------------------------------ resample planning
+namespace {
+
+// One layer that needs Image.resize: up to two axis passes through the arena.
+struct ResizePlan {
+    uint64_t src;
+    int sw, sh, dw, dh;
+    size_t tmp_off = 0;   // arena offset of the horizontal pass output (if both axes change)
+    size_t dst_off = 0;   // arena offset of the final image (unused when dst_ptr is set)
+    uint64_t dst_ptr = 0; // caller-provided destination (mic_resize)
+};
+
+struct PassTables {
+    std::vector<RsJob> h, v;
+    int max_h_out_w = 0, max_h_rows = 0, max_v_out_w = 0, max_v_out_h = 0;
+};
+
+int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, PassTables *pt) {
+    const uint64_t arena = reinterpret_cast<uint64_t>(ctx->arena);
+    for (const ResizePlan &p : plans) {
+        const bool need_h = p.dw != p.sw, need_v = p.dh != p.sh;
+        const uint64_t dst = p.dst_ptr ? p.dst_ptr : arena + p.dst_off;
+        uint64_t v_src = p.src;
+        uint32_t v_flags = kRsUnpremultiplyOnStore | kRsPremultiplyOnLoad;
+        if (need_h) {
+            CoefEntry ce;
+            if (int rc = get_coefs(ctx, p.sw, p.dw, filter, true, &ce)) return rc;
+            RsJob j{};
+            j.src = p.src;
+            j.dst = need_v ? arena + p.tmp_off : dst;
+            j.bounds = reinterpret_cast<uint64_t>(ce.bounds);
+            j.coeffs = reinterpret_cast<uint64_t>(ce.coeffs);
+            j.in_w = p.sw; j.in_h = p.sh; j.out_w = p.dw; j.out_h = p.sh;
+            j.ksize = ce.ksize;
+            j.flags = kRsPremultiplyOnLoad | (need_v ? 0u : (uint32_t)kRsUnpremultiplyOnStore);
+            pt->h.push_back(j);
+            pt->max_h_out_w = std::max(pt->max_h_out_w, p.dw);
+            pt->max_h_rows = std::max(pt->max_h_rows, p.sh);
+            v_src = j.dst;
+            v_flags = kRsUnpremultiplyOnStore;
+        }
+        if (need_v) {
+            CoefEntry ce;
+            if (int rc = get_coefs(ctx, p.sh, p.dh, filter, false, &ce)) return rc;
+            RsJob j{};
+            j.src = v_src;
+            j.dst = dst;
+            j.bounds = reinterpret_cast<uint64_t>(ce.bounds);
+            j.coeffs = reinterpret_cast<uint64_t>(ce.coeffs);
+            j.in_w = p.dw; j.in_h = p.sh; j.out_w = p.dw; j.out_h = p.dh;
+            j.ksize = ce.ksize;
+            j.flags = v_flags;
+            pt->v.push_back(j);
+            pt->max_v_out_w = std::max(pt->max_v_out_w, p.dw);
+            pt->max_v_out_h = std::max(pt->max_v_out_h, p.dh);
+        }
+    }
+    return MIC_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ composite
+extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,
+                                   const mic_job *jobs, int filter, void *stream_v) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (n_jobs < 0 || n_atlases < 0 || (n_jobs > 0 && !jobs) || (n_atlases > 0 && !atlases))
+        return fail(MIC_ERR_INVALID, "mic_composite_batch: bad arguments");
+    if (filter != MIC_FILTER_LANCZOS && filter != MIC_FILTER_BILINEAR)
+        return fail(MIC_ERR_INVALID, "unknown filter %d", filter);
+    if (n_jobs > 65535) return fail(MIC_ERR_INVALID, "at most 65535 jobs per call");
+    for (int a = 0; a < n_atlases; ++a)
+        if (!atlases[a] || atlases[a]->ctx != ctx)
+            return fail(MIC_ERR_INVALID, "atlas %d is null or belongs to another context", a);
+    if (int rc = adopt_stream(ctx, stream)) return rc;
+    mic_stats st{};
+    if (n_jobs == 0) {
+        ctx->stats = st;
+        return MIC_OK;
+    }
+
+    std::vector<Job> djobs((size_t)n_jobs);
+    std::vector<Layer> dlayers;
+    std::vector<ResizePlan> plans;
+    struct Pending { size_t layer; size_t plan; };
+    std::vector<Pending> pending;  // layers whose src is an arena offset, patched after ensure_arena
+    std::map<std::tuple<uint64_t, int, int, int>, size_t> dedup;  // (atlas uid, entry, w, h) -> plan
+    size_t arena_need = 0;
+    int max_tiles = 0;
+
+    for (int ji = 0; ji < n_jobs; ++ji) {
+        const mic_job &J = jobs[ji];
+        if (J.width <= 0 || J.height <= 0 || J.width > kMaxDim || J.height > kMaxDim)
+            return fail(MIC_ERR_INVALID, "job %d: invalid canvas size %dx%d", ji, J.width, J.height);
+        if (!J.out_dev) return fail(MIC_ERR_INVALID, "job %d: null output canvas", ji);
+        if (J.out_dev == J.bg_dev) return fail(MIC_ERR_INVALID, "job %d: output aliases the background", ji);
+        if (J.n_placements < 0 || (J.n_placements > 0 && !J.placements))
+            return fail(MIC_ERR_INVALID, "job %d: bad placement list", ji);
+        Job d{};
+        d.out = reinterpret_cast<uint64_t>(J.out_dev);
+        d.bg = reinterpret_cast<uint64_t>(J.bg_dev);
+        d.bg_rgba = (uint32_t)J.bg_rgba[0] | ((uint32_t)J.bg_rgba[1] << 8) | ((uint32_t)J.bg_rgba[2] << 16) |
+                    ((uint32_t)J.bg_rgba[3] << 24);
+        d.W = J.width;
+        d.H = J.height;
+        d.layer_begin = (int32_t)dlayers.size();
+        d.tiles_x = (J.width + kTileW - 1) / kTileW;
+        d.tiles_y = (J.height + kTileH - 1) / kTileH;
+        max_tiles = std::max(max_tiles, d.tiles_x * d.tiles_y);
+        st.canvas_pixels += (uint64_t)J.width * J.height;
+
+        for (int pi = 0; pi < J.n_placements; ++pi) {
+            const mic_placement &P = J.placements[pi];
+            if (P.atlas < 0 || P.atlas >= n_atlases)
+                return fail(MIC_ERR_INVALID, "job %d placement %d: atlas index %d out of range", ji, pi, P.atlas);
+            const mic_atlas *A = atlases[P.atlas];
+            auto it = A->index.find(P.object_id);
+            if (it == A->index.end()) {  // compositor.py:14-15
+                ++st.skipped_placements;
+                continue;
+            }
+            const BlobEntry &E = A->entries[it->second];
+            const int64_t x1 = P.box[0], y1 = P.box[1];
+            const int64_t w = std::max<int64_t>(1, (int64_t)P.box[2] - x1);
+            const int64_t h = std::max<int64_t>(1, (int64_t)P.box[3] - y1);
+            // in-canvas part of the layer; layers that miss the canvas have no effect at all
+            const int64_t vx0 = std::max<int64_t>(x1, 0), vx1 = std::min<int64_t>(x1 + w, J.width);
+            const int64_t vy0 = std::max<int64_t>(y1, 0), vy1 = std::min<int64_t>(y1 + h, J.height);
+            if (vx0 >= vx1 || vy0 >= vy1) continue;
+            if (w > kMaxDim || h > kMaxDim)
+                return fail(MIC_ERR_INVALID, "job %d placement %d: box %lldx%lld exceeds %lld", ji, pi,
+                            (long long)w, (long long)h, (long long)kMaxDim);
+            Layer L{};
+            L.dx = (int32_t)x1; L.dy = (int32_t)y1; L.w = (int32_t)w; L.h = (int32_t)h;
+            st.layer_pixels += (uint64_t)(vx1 - vx0) * (vy1 - vy0);
+            st.source_pixels += (uint64_t)E.w * E.h;
+            if (w == E.w && h == E.h) {
+                L.src = reinterpret_cast<uint64_t>(A->blob) + E.offset;
+                ++st.identity_layers;
+            } else {
+                ++st.resampled_layers;
+                auto key = std::make_tuple(A->uid, it->second, (int)w, (int)h);
+                auto dit = dedup.find(key);
+                size_t plan_idx;
+                if (dit != dedup.end()) {
+                    plan_idx = dit->second;
+                } else {
+                    ResizePlan rp{};
+                    rp.src = reinterpret_cast<uint64_t>(A->blob) + E.offset;
+                    rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
+                    if (rp.dw != rp.sw && rp.dh != rp.sh) {
+                        rp.tmp_off = arena_need;
+                        arena_need = align_up(arena_need + (size_t)rp.dw * rp.sh * 4, kPixelAlign);
+                    }
+                    rp.dst_off = arena_need;
+                    arena_need = align_up(arena_need + (size_t)rp.dw * rp.dh * 4, kPixelAlign);
+                    plan_idx = plans.size();
+                    plans.push_back(rp);
+                    dedup.emplace(key, plan_idx);
+                }
+                pending.push_back({dlayers.size(), plan_idx});
+            }
+            dlayers.push_back(L);
+        }
+        d.layer_count = (int32_t)dlayers.size() - d.layer_begin;
+        djobs[(size_t)ji] = d;
+    }
+
+    if (arena_need > ((size_t)64 << 30))
+        return fail(MIC_ERR_NOMEM, "resampled layers of this call need %zu bytes of scratch", arena_need);
+    if (int rc = ensure_arena(ctx, arena_need)) return rc;
+    for (const Pending &p : pending)
+        dlayers[p.layer].src = reinterpret_cast<uint64_t>(ctx->arena) + plans[p.plan].dst_off;
+    PassTables pt;
+    if (int rc = plan_passes(ctx, plans, filter, &pt)) return rc;
+
+    // ---- one params blob: jobs | layers | horizontal passes | vertical passes ----
+    const size_t off_jobs = 0;
+    const size_t off_layers = align_up(off_jobs + sizeof(Job) * djobs.size(), 64);
+    const size_t off_h = align_up(off_layers + sizeof(Layer) * dlayers.size(), 64);
+    const size_t off_v = align_up(off_h + sizeof(RsJob) * pt.h.size(), 64);
+    const size_t total = align_up(off_v + sizeof(RsJob) * pt.v.size(), 64);
+    Slot *slot = nullptr;
+    if (int rc = acquire_slot(ctx, total, &slot)) return rc;
+    char *hp = static_cast<char *>(slot->host);
+    memcpy(hp + off_jobs, djobs.data(), sizeof(Job) * djobs.size());
+    if (!dlayers.empty()) memcpy(hp + off_layers, dlayers.data(), sizeof(Layer) * dlayers.size());
+    if (!pt.h.empty()) memcpy(hp + off_h, pt.h.data(), sizeof(RsJob) * pt.h.size());
+    if (!pt.v.empty()) memcpy(hp + off_v, pt.v.data(), sizeof(RsJob) * pt.v.size());
+    HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, total, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(slot->ev, stream));
+    slot->pending = true;
+
+    char *dp = static_cast<char *>(slot->dev);
+    const bool prof = ctx->profiling && ctx->prof_calls < ctx->prof_max;
+    hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
+    if (prof) HIP_TRY(hipEventRecord(pe[0], stream));
+    HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + off_h), (int)pt.h.size(), pt.max_h_out_w,
+                              pt.max_h_rows, stream));
+    HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + off_v), (int)pt.v.size(), pt.max_v_out_w,
+                              pt.max_v_out_h, stream));
+    if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
+    HIP_TRY(launch_composite(reinterpret_cast<const Job *>(dp + off_jobs),
+                             reinterpret_cast<const Layer *>(dp + off_layers), n_jobs, max_tiles, stream));
+    if (prof) {
+        HIP_TRY(hipEventRecord(pe[2], stream));
+        ++ctx->prof_calls;
+    }
+    st.composite_blocks = (uint64_t)max_tiles * n_jobs;
+    ctx->stats = st;
+    return MIC_OK;
+}
+
+extern "C" int mic_last_stats(const mic_ctx *ctx, mic_stats *out) {
+    if (!ctx || !out) return fail(MIC_ERR_INVALID, "mic_last_stats: null argument");
+    *out = ctx->stats;
+    return MIC_OK;
+}
+
+extern "C" int mic_profile_begin(mic_ctx *ctx, int max_calls) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    if (max_calls <= 0 || max_calls > (1 << 20)) return fail(MIC_ERR_INVALID, "mic_profile_begin: bad max_calls");
+    while ((int)ctx->prof_events.size() < max_calls * 3) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        ctx->prof_events.push_back(ev);
+    }
+    ctx->prof_max = max_calls;
+    ctx->prof_calls = 0;
+    ctx->profiling = true;
+    return MIC_OK;
+}
+
+extern "C" int mic_profile_end(mic_ctx *ctx, void *stream, int *n_calls, double *composite_ms, double *resample_ms) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    if (!n_calls || !composite_ms || !resample_ms) return fail(MIC_ERR_INVALID, "mic_profile_end: null argument");
+    ctx->profiling = false;
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    double c = 0.0, r = 0.0;
+    for (int i = 0; i < ctx->prof_calls; ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_events[(size_t)i * 3], ctx->prof_events[(size_t)i * 3 + 1]));
+        r += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->prof_events[(size_t)i * 3 + 1], ctx->prof_events[(size_t)i * 3 + 2]));
+        c += ms;
+    }
+    *n_calls = ctx->prof_calls;
+    *composite_ms = c;
+    *resample_ms = r;
+    return MIC_OK;
+}
+
+// ------------------------------------------------------------------------------------ resize
+extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int32_t src_h, void *dst_dev,
+                          int32_t dst_w, int32_t dst_h, int filter, void *stream_v) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (!src_dev || !dst_dev) return fail(MIC_ERR_INVALID, "mic_resize: null image");
+    if (src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0 || src_w > kMaxDim || src_h > kMaxDim ||
+        dst_w > kMaxDim || dst_h > kMaxDim)
+        return fail(MIC_ERR_INVALID, "mic_resize: invalid size %dx%d -> %dx%d", src_w, src_h, dst_w, dst_h);
+    if (filter != MIC_FILTER_LANCZOS && filter != MIC_FILTER_BILINEAR)
+        return fail(MIC_ERR_INVALID, "unknown filter %d", filter);
+    if (int rc = adopt_stream(ctx, stream)) return rc;
+    if (src_w == dst_w && src_h == dst_h) {  // Image.resize returns a copy
+        HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, (size_t)src_w * src_h * 4, hipMemcpyDeviceToDevice, stream));
+        return MIC_OK;
+    }
+    ResizePlan rp{};
+    rp.src = reinterpret_cast<uint64_t>(src_dev);
+    rp.sw = src_w; rp.sh = src_h; rp.dw = dst_w; rp.dh = dst_h;
+    rp.dst_ptr = reinterpret_cast<uint64_t>(dst_dev);
+    size_t need = 0;
+    if (dst_w != src_w && dst_h != src_h) need = (size_t)dst_w * src_h * 4;
+    if (int rc = ensure_arena(ctx, need)) return rc;
+    PassTables pt;
+    std::vector<ResizePlan> plans{rp};
+    if (int rc = plan_passes(ctx, plans, filter, &pt)) return rc;
+    const size_t off_v = 64;
+    Slot *slot = nullptr;
+    if (int rc = acquire_slot(ctx, 128, &slot)) return rc;
+    char *hp = static_cast<char *>(slot->host);
+    if (!pt.h.empty()) memcpy(hp, pt.h.data(), sizeof(RsJob));
+    if (!pt.v.empty()) memcpy(hp + off_v, pt.v.data(), sizeof(RsJob));
+    HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, 128, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(slot->ev, stream));
+    slot->pending = true;
+    char *dp = static_cast<char *>(slot->dev);
+    HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp), (int)pt.h.size(), pt.max_h_out_w,
+                              pt.max_h_rows, stream));
+    HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + off_v), (int)pt.v.size(), pt.max_v_out_w,
+                              pt.max_v_out_h, stream));
+    return MIC_OK;
+}
+
+// ------------------------------------------------------------------------------------ background
+extern "C" int mic_median_rgb_dev(mic_ctx *ctx, const void *rgba_dev, int32_t width, int32_t height,
+                                  void *rgba_out_dev, void *stream_v) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (!rgba_dev || !rgba_out_dev || width <= 0 || height <= 0)
+        return fail(MIC_ERR_INVALID, "mic_median_rgb: bad arguments");
+    if (int rc = adopt_stream(ctx, stream)) return rc;
+    HIP_TRY(launch_median(rgba_dev, (size_t)width * height, ctx->median_scratch,
+                          static_cast<uint32_t *>(rgba_out_dev), stream));
+    return MIC_OK;
+}
+
+extern "C" int mic_median_rgb(mic_ctx *ctx, const void *rgba_dev, int32_t width, int32_t height,
+                              uint8_t out_rgb[3], void *stream_v) {
+    if (!out_rgb) return fail(MIC_ERR_INVALID, "mic_median_rgb: null result");
+    if (!ctx) return fail(MIC_ERR_INVALID, "null context");
+    uint32_t *res_dev = ctx->median_scratch + kMedianScratchWords;
+    if (int rc = mic_median_rgb_dev(ctx, rgba_dev, width, height, res_dev, stream_v)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    HIP_TRY(hipMemcpyAsync(ctx->median_host, res_dev, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint32_t v = ctx->median_host[0];
+    out_rgb[0] = (uint8_t)(v & 255u);
+    out_rgb[1] = (uint8_t)((v >> 8) & 255u);
+    out_rgb[2] = (uint8_t)((v >> 16) & 255u);
+    return MIC_OK;
+}
+
+extern "C" int mic_fill_solid(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height,
+                              const uint8_t rgba[4], void *stream_v) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    if (!out_dev || !rgba || width <= 0 || height <= 0) return fail(MIC_ERR_INVALID, "mic_fill_solid: bad arguments");
+    const uint32_t c = (uint32_t)rgba[0] | ((uint32_t)rgba[1] << 8) | ((uint32_t)rgba[2] << 16) | ((uint32_t)rgba[3] << 24);
+    HIP_TRY(launch_fill(out_dev, c, (size_t)width * height, static_cast<hipStream_t>(stream_v)));
+    return MIC_OK;
+}
+
+extern "C" int mic_thumbnail_size(int32_t w, int32_t h, int32_t req_w, int32_t req_h, int32_t *out_w,
+                                  int32_t *out_h) {
+    if (!out_w || !out_h || w <= 0 || h <= 0 || req_w <= 0 || req_h <= 0)
+        return fail(MIC_ERR_INVALID, "mic_thumbnail_size: bad arguments");
+    int ow = 0, oh = 0;
+    thumbnail_size(w, h, req_w, req_h, &ow, &oh);
+    *out_w = ow;
+    *out_h = oh;
+    return MIC_OK;
+}

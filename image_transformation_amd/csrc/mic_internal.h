@@ -1,0 +1,78 @@
+// Internal declarations shared by the host runtime (mic_api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mic {
+
+// Device addresses travel as integers inside the job tables; casting them to address space 1
+// makes the compiler emit global_load/global_store instead of flat_*.
+#define MIC_GLOBAL __attribute__((address_space(1)))
+typedef const MIC_GLOBAL uint32_t *gcptr;
+typedef MIC_GLOBAL uint32_t *gptr;
+typedef const MIC_GLOBAL int32_t *gciptr;
+
+// ---- composite ---------------------------------------------------------------------------
+constexpr int kLaneNPx = 4;                  // pixels per lane per row (16 B)
+constexpr int kTileW = 64 * kLaneNPx;        // one wavefront spans 256 px = 1 KiB per row
+constexpr int kRowsPerWave = 4;
+constexpr int kWavesPerBlock = 4;
+constexpr int kTileH = kRowsPerWave * kWavesPerBlock;
+
+// One resolved placement: where the layer's pixels live and where they land on the canvas.
+struct alignas(16) Layer {
+    uint64_t src;      // device address of w*h RGBA pixels, row stride = w
+    int32_t dx, dy;    // canvas position of the layer's top-left pixel (may be negative)
+    int32_t w, h;      // layer size (box size after the max(1, .) rule)
+    int32_t pad0, pad1;
+};
+static_assert(sizeof(Layer) == 32, "Layer layout");
+
+// One canvas.
+struct alignas(16) Job {
+    uint64_t out;      // device address of the W*H canvas
+    uint64_t bg;       // device address of a W*H background image, 0 = solid colour
+    uint32_t bg_rgba;  // solid colour, little-endian r | g<<8 | b<<16 | a<<24
+    int32_t W, H;
+    int32_t layer_begin, layer_count;
+    int32_t tiles_x, tiles_y;
+    int32_t pad0;
+};
+static_assert(sizeof(Job) == 48, "Job layout");
+
+// ---- resample ------------------------------------------------------------------------------
+constexpr int kPrecisionBits = 22;           // Pillow Resample.c: 32 - 8 - 2
+
+enum RsFlags : uint32_t {
+    kRsPremultiplyOnLoad = 1,   // input is straight RGBA: premultiply each tap (Convert.c rgbA2rgba)
+    kRsUnpremultiplyOnStore = 2 // output is the final image: RGBa -> RGBA (Convert.c rgba2rgbA)
+};
+
+// One axis pass of one layer.  Horizontal: out(x', y) = sum_k in(xmin[x'] + k, y) * K[x'][k];
+// vertical: the same along y.  bounds/coeffs live in the context's coefficient arena.
+struct alignas(16) RsJob {
+    uint64_t src, dst;
+    uint64_t bounds;   // int32 [out_len][2] = (first tap, tap count)
+    uint64_t coeffs;   // int32 [out_len][ksize]
+    int32_t in_w, in_h;
+    int32_t out_w, out_h;
+    int32_t ksize;
+    uint32_t flags;
+    int32_t pad0, pad1;
+};
+static_assert(sizeof(RsJob) == 64, "RsJob layout");
+
+// ---- launchers (defined next to their kernels) -----------------------------------------------
+hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_jobs,
+                            int max_tiles, hipStream_t stream);
+hipError_t launch_resample_h(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_rows,
+                             hipStream_t stream);
+hipError_t launch_resample_v(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_out_h,
+                             hipStream_t stream);
+hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);
+// hist: uint32 [2][3][256] + counts[2]; zeroed by the launcher.
+hipError_t launch_median(const void *rgba, size_t n_px, uint32_t *hist_dev, uint32_t *out_rgba_dev,
+                         hipStream_t stream);
+constexpr size_t kMedianScratchWords = 2 * 3 * 256 + 8;
+
+}  // namespace mic

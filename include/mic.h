@@ -1,0 +1,158 @@
+/*
+ * mic.h -- C ABI of the MI355X-native compositor (libmic.so).
+ *
+ * The reference (FelixMul/image_transformation) has no FFI: its pixel path is three
+ * importable Python callables that delegate the arithmetic to Pillow / NumPy.  This
+ * header is the boundary a binding for that path would attach to; each entry point
+ * names the reference interface it replaces (file:line under /root/reference).
+ * The Python package image_transformation_amd binds it with ctypes (see
+ * image_transformation_amd/_native.py) and keeps the reference's call surface.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative mic_status on failure;
+ *     mic_last_error() returns a thread-local message for the last failure;
+ *   - no exceptions cross the boundary; no torch types appear in any signature;
+ *   - pixel buffers are RGBA8, interleaved, row-major, non-premultiplied, top-left origin
+ *     (Pillow mode "RGBA"), row stride = width * 4 bytes;
+ *   - "dev" pointers are device memory of the context's GPU (e.g. a torch tensor's
+ *     data_ptr()); "host" pointers are ordinary memory owned by the caller;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is
+ *     enqueued asynchronously on it; outputs are complete once the stream has drained.
+ *     A context must be driven from one stream at a time.
+ *   - there is NO CPU fallback: without a usable HIP device mic_create fails.
+ */
+#ifndef MIC_H
+#define MIC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mic_ctx mic_ctx;     /* per-process, per-device state (tables, scratch arena) */
+typedef struct mic_atlas mic_atlas; /* device-resident packed cutouts + id/size table        */
+
+enum mic_status {
+    MIC_OK = 0,
+    MIC_ERR_INVALID = -1,   /* bad argument                                    */
+    MIC_ERR_HIP = -2,       /* a HIP runtime call failed (message has details) */
+    MIC_ERR_NOMEM = -3,     /* host or device allocation failed                */
+    MIC_ERR_NODEVICE = -4,  /* no usable gfx950 device                         */
+    MIC_ERR_FORMAT = -5     /* malformed atlas blob                            */
+};
+
+enum mic_filter {
+    MIC_FILTER_LANCZOS = 0, /* Pillow Image.LANCZOS (a = 3): what compositor.py:20 asks for */
+    MIC_FILTER_BILINEAR = 1 /* Pillow Image.BILINEAR, same fixed-point machinery            */
+};
+
+const char *mic_last_error(void);
+/* Library/ABI version: major << 16 | minor. */
+int mic_version(void);
+
+/* ---- context --------------------------------------------------------------------------- */
+int mic_create(int device, mic_ctx **out);
+int mic_destroy(mic_ctx *ctx);
+/* Block until everything enqueued through this context on `stream` has finished. */
+int mic_sync(mic_ctx *ctx, void *stream);
+
+/* ---- atlas: replaces the dict returned by compositor.load_object_images -----------------
+ * (compositor.py:25-35: {int object_id: RGBA Image}).  The atlas is uploaded once per
+ * bundle and stays resident across composites / refine iterations / batches.            */
+
+/* Upload n cutouts from host memory into one device blob owned by the atlas. */
+int mic_atlas_create(mic_ctx *ctx, int n, const int32_t *ids, const int32_t *widths,
+                     const int32_t *heights, const uint8_t *const *rgba_host, mic_atlas **out);
+/* Bytes a blob for these cutouts needs (so a caller can allocate it as a torch tensor). */
+int mic_atlas_blob_size(int n, const int32_t *widths, const int32_t *heights, size_t *bytes);
+/* Write the blob header/table into host memory `blob_host` (bytes from mic_atlas_blob_size) and
+ * return per-object pixel offsets; the caller copies pixels to blob+offset[i] and uploads.  */
+int mic_atlas_blob_layout(int n, const int32_t *ids, const int32_t *widths, const int32_t *heights,
+                          void *blob_host, size_t bytes, uint64_t *pixel_offsets);
+/* Wrap a device blob (layout above; e.g. received by an RCCL broadcast).  The atlas does not
+ * own the memory: the caller keeps it alive until mic_atlas_destroy.  `header_host` may pass
+ * the first mic_atlas_header_bytes(n) bytes of the blob if the caller has them on the host,
+ * otherwise NULL and the header is read back from the device.                              */
+int mic_atlas_from_device_blob(mic_ctx *ctx, const void *blob_dev, size_t bytes,
+                               const void *header_host, mic_atlas **out);
+int mic_atlas_device_blob(const mic_atlas *atlas, const void **blob_dev, size_t *bytes);
+int mic_atlas_count(const mic_atlas *atlas);
+/* Size / device address of one cutout; MIC_ERR_INVALID if the id is unknown. */
+int mic_atlas_lookup(const mic_atlas *atlas, int32_t id, int32_t *width, int32_t *height,
+                     const void **rgba_dev);
+int mic_atlas_destroy(mic_atlas *atlas);
+
+/* ---- composite: replaces compositor.composite (compositor.py:6-22) -------------------------
+ * One job = one canvas: start from the background (a device image, or a solid colour that is
+ * synthesised in-kernel: background_resizing.py:32), then for each placement IN LIST ORDER:
+ * w = max(1, x2-x1), h = max(1, y2-y1); the cutout is resized to (w,h) with `filter` exactly
+ * as Pillow does (identity size = no resampling) and alpha-composited at (x1,y1), clipped to
+ * the canvas, with 8-bit rounding after every layer (Pillow AlphaComposite.c).  Placements whose
+ * object id is not in their atlas are skipped (compositor.py:14-15).  Box coordinates are
+ * already integers here: int() coercion of JSON values is the Python binding's job.        */
+typedef struct mic_placement {
+    int32_t atlas;     /* index into the `atlases` array of the call */
+    int32_t object_id; /* id inside that atlas                       */
+    int32_t box[4];    /* x1, y1, x2, y2 on the canvas               */
+} mic_placement;
+
+typedef struct mic_job {
+    int32_t width, height;           /* canvas size                                       */
+    const void *bg_dev;              /* device RGBA background image, or NULL for solid    */
+    uint8_t bg_rgba[4];              /* solid background colour when bg_dev == NULL       */
+    int32_t n_placements;
+    const mic_placement *placements; /* host array                                        */
+    void *out_dev;                   /* device RGBA canvas, width*height*4 bytes; must not
+                                        alias bg_dev (compositor.py:11 copies the bg)      */
+} mic_job;
+
+int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,
+                        const mic_job *jobs, int filter, void *stream);
+
+/* Image.resize((out_w,out_h), filter) of one device RGBA image (compositor.py:20 call shape;
+ * also the thumbnail resample of macro_placement_test.py:194).                             */
+int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int32_t src_h, void *dst_dev,
+               int32_t dst_w, int32_t dst_h, int filter, void *stream);
+
+/* ---- background synthesis: replaces background_resizing.py:11-33 ------------------------- */
+/* _median_color_nontransparent: per-channel median over pixels with alpha > 0 (all pixels if
+ * none), int() truncation.  Result written to host out_rgb after an internal stream sync.   */
+int mic_median_rgb(mic_ctx *ctx, const void *rgba_dev, int32_t width, int32_t height,
+                   uint8_t out_rgb[3], void *stream);
+/* Same, result left on the device as 4 bytes r,g,b,255 at rgba_out_dev (no host sync).      */
+int mic_median_rgb_dev(mic_ctx *ctx, const void *rgba_dev, int32_t width, int32_t height,
+                       void *rgba_out_dev, void *stream);
+/* Image.new("RGBA", (w,h), colour) on the device (background_resizing.py:32).               */
+int mic_fill_solid(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height,
+                   const uint8_t rgba[4], void *stream);
+
+/* ---- helpers ----------------------------------------------------------------------------- */
+/* Pillow Image.thumbnail size rule (macro_placement_test.py:194). */
+int mic_thumbnail_size(int32_t w, int32_t h, int32_t req_w, int32_t req_h, int32_t *out_w,
+                       int32_t *out_h);
+/* Counters of the last mic_composite_batch call on this context (for bench/roofline):
+ * algorithmic bytes = 4*W*H per canvas + 4*visible source pixels read.                     */
+typedef struct mic_stats {
+    uint64_t canvas_pixels;       /* sum of W*H over jobs                                */
+    uint64_t layer_pixels;        /* sum of in-canvas layer pixels (alpha-over operations)  */
+    uint64_t source_pixels;       /* sum of cutout pixels referenced (each cutout counted per use) */
+    uint64_t resampled_layers;    /* layers that needed a resize                           */
+    uint64_t identity_layers;
+    uint64_t skipped_placements;  /* unknown ids                                           */
+    uint64_t composite_blocks;    /* workgroups launched by the composite kernel           */
+} mic_stats;
+int mic_last_stats(const mic_ctx *ctx, mic_stats *out);
+
+/* Kernel timing with HIP events recorded on the launch stream, for bench.py's roofline: between
+ * mic_profile_begin and mic_profile_end every mic_composite_batch call brackets its composite
+ * kernel (and, separately, its resample passes) with an event pair.  mic_profile_end waits for
+ * the stream, then reports the number of bracketed calls and the summed durations in ms.       */
+int mic_profile_begin(mic_ctx *ctx, int max_calls);
+int mic_profile_end(mic_ctx *ctx, void *stream, int *n_calls, double *composite_ms, double *resample_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIC_H */

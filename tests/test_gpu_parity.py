@@ -1,0 +1,373 @@
+"""GPU parity: the HIP path (through the C ABI, via the package's reference-shaped call surface)
+against the CPU oracle on the same seeded inputs and against the fixtures captured from the
+reference.  Bar: bit-exact (8-bit integer arithmetic), which is inside north_star's +-1 LSB.
+
+Nothing here reads /root/reference; inputs are regenerated from seeds or come from
+tests/golden/bundles (data files).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import cases  # noqa: E402
+import oracle  # noqa: E402  (the checker)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need an MI355X; none is visible")
+    from image_transformation_amd import _native
+    ctx = _native.context()  # raises loudly if libmic.so is missing
+    return ctx
+
+
+def _load(golden_dir, stem):
+    with open(os.path.join(golden_dir, stem + ".json"), encoding="utf-8") as f:
+        meta = json.load(f)
+    p = os.path.join(golden_dir, stem + ".npz")
+    return meta, (np.load(p) if os.path.exists(p) else None)
+
+
+def _img(a):
+    from PIL import Image
+    return Image.fromarray(np.ascontiguousarray(a), "RGBA")
+
+
+def _arr(im):
+    return np.array(im)
+
+
+def _maxdiff(a, b):
+    return int(np.abs(a.astype(np.int32) - b.astype(np.int32)).max()) if a.shape == b.shape else -1
+
+
+# ------------------------------------------------------------------------------------------ composite()
+def test_composite_golden_cases(gpu, golden_dir):
+    from image_transformation_amd.compositor import composite
+    meta, arrays = _load(golden_dir, "composite")
+    by_name = {c["name"]: c for c in cases.composite_cases()}
+    for row in meta["cases"]:
+        c = by_name[row["name"]]
+        bg = _img(c["bg"])
+        before = bg.tobytes()
+        got = _arr(composite(bg, {k: _img(v) for k, v in c["objects"].items()}, c["placements"]))
+        assert bg.tobytes() == before, "background must not be modified (compositor.py:11)"
+        want = arrays[row["name"]]
+        assert np.array_equal(got, want), (row["name"], _maxdiff(got, want))
+        assert np.array_equal(got, oracle.composite(c["bg"], c["objects"], c["placements"]))
+
+
+def test_reference_unit_test_restated(gpu):
+    """tests/test_compositor.py:5-11 of the reference, against this package."""
+    from PIL import Image
+    from image_transformation_amd.compositor import composite
+    bg = Image.new("RGBA", (10, 10), (255, 0, 0, 255))
+    obj = Image.new("RGBA", (2, 2), (0, 255, 0, 255))
+    out = composite(bg, {1: obj}, [{"object_id": 1, "box": [4, 4, 6, 6]}])
+    assert out.getpixel((4, 4))[:3] == (0, 255, 0)
+    assert out.mode == "RGBA" and out.size == (10, 10)
+
+
+def test_composite_error_behaviour(gpu):
+    from PIL import Image
+    from image_transformation_amd.compositor import composite
+    bg = Image.new("RGBA", (8, 8), (1, 2, 3, 255))
+    obj = {1: Image.new("RGBA", (2, 2), (0, 255, 0, 255))}
+    with pytest.raises(ValueError):
+        composite(bg, obj, [{"object_id": "one", "box": [0, 0, 2, 2]}])       # int() of a non-number
+    with pytest.raises(ValueError):
+        composite(bg, obj, [{"object_id": 1, "box": [0, 0, 2]}])               # unpack
+    with pytest.raises((ValueError, TypeError)):
+        composite(bg, obj, [{"object_id": 1, "box": [0, 0, None, 2]}])
+    with pytest.raises(KeyError):
+        composite(bg, obj, [{"box": [0, 0, 2, 2]}])
+    with pytest.raises(ValueError, match="wrong mode"):
+        composite(bg.convert("RGB"), obj, [{"object_id": 1, "box": [0, 0, 2, 2]}])
+    with pytest.raises(ValueError, match="wrong mode"):
+        composite(bg, {1: obj[1].convert("RGB")}, [{"object_id": 1, "box": [0, 0, 2, 2]}])
+    out = composite(bg, obj, [{"object_id": 5, "box": [0, 0, 2, 2]}])          # unknown id: skipped
+    assert out.tobytes() == bg.tobytes() and out is not bg
+
+
+# ------------------------------------------------------------------------------------------ resize
+def test_resize_golden_cases(gpu, golden_dir):
+    import ctypes
+    import torch
+    from image_transformation_amd import _native
+    meta, arrays = _load(golden_dir, "resize")
+    lib = _native.lib()
+    for i, row in enumerate(meta["cases"]):
+        c = cases.resize_case(i)
+        src = torch.from_numpy(c["src"]).to(gpu.torch_device)
+        for filt, key in ((_native.LANCZOS, row["name"]), (_native.BILINEAR, row["name"] + "_bilinear")):
+            dw, dh = c["size"]
+            dst = torch.empty((dh, dw, 4), dtype=torch.uint8, device=gpu.torch_device)
+            _native.check(lib.mic_resize(gpu.handle, ctypes.c_void_p(src.data_ptr()), c["src"].shape[1],
+                                         c["src"].shape[0], ctypes.c_void_p(dst.data_ptr()), dw, dh, filt,
+                                         ctypes.c_void_p(gpu.stream_ptr())))
+            got = dst.cpu().numpy()
+            assert np.array_equal(got, arrays[key]), (key, _maxdiff(got, arrays[key]))
+
+
+# ------------------------------------------------------------------------------------------ median / fill_solid
+def test_median_cases(gpu, golden_dir):
+    from image_transformation_amd.background_resizing import _median_color_nontransparent
+    meta, _ = _load(golden_dir, "median")
+    rows = {r["name"]: r for r in meta["cases"]}
+    for i in range(cases.N_MEDIAN):
+        c = cases.median_case(i)
+        assert list(_median_color_nontransparent(_img(c["rgba"]))) == rows[c["name"]]["rgb"], c["name"]
+
+
+def test_median_large_random_vs_oracle(gpu):
+    import torch
+    from image_transformation_amd.background_resizing import median_color_device
+    rng = np.random.default_rng(7)
+    for (h, w, mode) in [(2160, 3840, "noise"), (1081, 1923, "flat"), (777, 1234, "sparse")]:
+        a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        if mode == "flat":      # backgrounds are mostly one colour: the wave-aggregation path
+            a[:, :, :3] = (38, 73, 115)
+            a[::7, ::5, :3] = rng.integers(0, 256, a[::7, ::5, :3].shape, dtype=np.uint8)
+        if mode == "sparse":
+            a[:, :, 3] = np.where(rng.random((h, w)) < 0.01, 255, 0)
+        assert median_color_device(torch.from_numpy(a).to(gpu.torch_device)) == oracle.median_rgb(a), mode
+
+
+def test_fill_solid_bundles(gpu, golden_dir):
+    from image_transformation_amd.background_resizing import fill_solid, solid_canvas
+    meta, _ = _load(golden_dir, "median")
+    rows = {r["name"]: r for r in meta["cases"]}
+    for b in cases.BUNDLES:
+        path = os.path.join(cases.BUNDLE_DIR, b, "background.png")
+        img = fill_solid(path, (33, 17))
+        assert img.mode == "RGBA" and img.size == (33, 17)
+        a = _arr(img)
+        want = rows[f"bundle_{b}"]["rgb"] + [255]
+        assert (a == np.asarray(want, np.uint8)).all()
+        assert list(solid_canvas(path, (5, 5)).rgba) == want
+    with pytest.raises(FileNotFoundError):
+        fill_solid(os.path.join(cases.BUNDLE_DIR, "nope.png"), (4, 4))
+
+
+# ------------------------------------------------------------------------------------------ render(): C1 + App. A.6
+def test_render_bundles_c1(gpu, golden_dir):
+    """BASELINE.json configs[0]: squarespace 1:1 (and the other bundle/ratio rows of App. A.6)."""
+    from image_transformation_amd.background_resizing import fill_solid, solid_canvas
+    from image_transformation_amd.compositor import composite, load_object_images, render
+    from image_transformation_amd.layout_constraints import compute_canvas_size
+    meta, arrays = _load(golden_dir, "bundles")
+    for row in meta["cases"]:
+        base = os.path.join(cases.BUNDLE_DIR, row["bundle"])
+        objects = load_object_images(os.path.join(base, "results.json"))
+        W, H = row["canvas"]
+        if "ratio" in row:
+            from PIL import Image
+            with Image.open(os.path.join(base, "background.png")) as im:
+                assert compute_canvas_size(im.size, row["ratio"], quiet=True) == (W, H)
+        bgp = os.path.join(base, "background.png")
+        if "placements" in row:
+            out = composite(fill_solid(bgp, (W, H)), objects, row["placements"])
+        else:
+            keep = {c["object_id"] for c in row["layout"]["root"]["children"]}
+            sub = {k: v for k, v in objects.items() if k in keep}
+            out = render(row["layout"], sub, solid_canvas(bgp, (W, H)))
+            out2 = render(row["layout"], sub, fill_solid(bgp, (W, H)))  # image background path
+            assert out.tobytes() == out2.tobytes()
+        got = _arr(out)
+        assert cases.sha16(got) == row["sha16"], row["name"]
+        if row["name"] in arrays.files:
+            assert np.array_equal(got, arrays[row["name"]])
+        if "centre_px" in row:
+            assert [int(v) for v in got[H // 2, W // 2]] == row["centre_px"]
+
+
+# ------------------------------------------------------------------------------------------ contact sheet
+def test_contact_sheet(gpu, golden_dir):
+    from image_transformation_amd.contact_sheet import build_labeled_contact_sheet, thumbnail_size
+    meta, arrays = _load(golden_dir, "contact_sheet")
+    for r in meta["thumbnail_sizes"]:
+        assert list(thumbnail_size(r["src"], (256, 256))) == r["size"]
+    for row in meta["cases"]:
+        if row.get("bundle") is None:
+            continue
+        b = row["bundle"]
+        rj = os.path.join(cases.BUNDLE_DIR, b, "results.json")
+        sheet = _arr(build_labeled_contact_sheet(os.path.join(cases.BUNDLE_DIR, b, "objects"), rj))
+        want = arrays[f"{b}_sheet"]
+        assert list(sheet.shape) == row["sheet_shape"]
+        # thumbnail area of every cell: bit-exact (LANCZOS thumbnail + alpha-over on white)
+        assert np.array_equal(sheet[:256], want[:256]), _maxdiff(sheet[:256], want[:256])
+        # label band: glyphs come from the host's FreeType; identical when the font stack matches
+        if cases.sha16(sheet) != row["sheet_sha16"]:
+            diff = (sheet != want).any(axis=2)
+            assert not diff[:256].any()
+            assert diff.sum() < 0.02 * diff.size, "label band differs by more than glyph rasterisation"
+    # empty bundle -> one blank cell (macro_placement_test.py:198-199)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        with open(os.path.join(d, "results.json"), "w") as f:
+            f.write("[]")
+        blank = build_labeled_contact_sheet(d, os.path.join(d, "results.json"))
+        assert blank.size == (256, 328) and blank.getpixel((0, 0)) == (255, 255, 255, 255)
+
+
+def test_big_thumbnail_hash(gpu, golden_dir):
+    import ctypes
+    import torch
+    from image_transformation_amd import _native
+    meta, _ = _load(golden_dir, "contact_sheet")
+    row = [r for r in meta["cases"] if r.get("bundle") is None][0]
+    big = cases.synthetic.make_cutout(np.random.default_rng(50_001), 1000, 800, "soft")
+    tw, th = row["size"]
+    src = torch.from_numpy(big).to(gpu.torch_device)
+    dst = torch.empty((th, tw, 4), dtype=torch.uint8, device=gpu.torch_device)
+    _native.check(_native.lib().mic_resize(gpu.handle, ctypes.c_void_p(src.data_ptr()), 1000, 800,
+                                           ctypes.c_void_p(dst.data_ptr()), tw, th, _native.LANCZOS,
+                                           ctypes.c_void_p(gpu.stream_ptr())))
+    assert cases.sha16(dst.cpu().numpy()) == row["sha16"]
+
+
+# ------------------------------------------------------------------------------------------ full-size configs
+def _big(golden_dir):
+    meta, _ = _load(golden_dir, "big_hashes")
+    return {r["name"]: r for r in meta["cases"]}
+
+
+def _solid(W, H):
+    a = np.empty((H, W, 4), np.uint8)
+    a[:] = np.asarray(cases.synthetic.SOLID_BG, np.uint8)
+    return a
+
+
+@pytest.mark.parametrize("alpha_mode", ["binary", "soft"])
+def test_c2_c3_flex_full_size(gpu, golden_dir, alpha_mode):
+    """BASELINE.json configs[1] and [2] at full size: Flex layout -> render_batch -> hash of the
+    reference's output, plus equality with the oracle on the same placements."""
+    from image_transformation_amd import flex
+    from image_transformation_amd.compositor import Atlas, SolidCanvas, render_batch
+    big = _big(golden_dir)
+    syn = cases.synthetic
+    size, objs, layout = syn.c2_workload(alpha_mode)
+    atlas = Atlas(objs)
+    out = render_batch([layout], atlas, [SolidCanvas(size, syn.SOLID_BG)])[0].cpu().numpy()
+    row = big[f"c2_flex_{alpha_mode}"]
+    pl = flex.layout_to_placements(layout, atlas, size)
+    assert [p["box"] for p in pl] == row["boxes"]
+    assert cases.sha16(out) == row["sha16"]
+    assert np.array_equal(out, oracle.composite(_solid(*size), objs, pl))
+
+    size, objs, layouts = syn.c3_workload(alpha_mode, n_layouts=3)
+    atlas = Atlas(objs)
+    outs = render_batch(layouts, atlas, [SolidCanvas(size, syn.SOLID_BG)] * 3)
+    for k, (layout, o) in enumerate(zip(layouts, outs)):
+        row = big[f"c3_flex_{alpha_mode}_{k}"]
+        pl = flex.layout_to_placements(layout, atlas, size)
+        assert [p["box"] for p in pl] == row["boxes"]
+        got = o.cpu().numpy()
+        assert cases.sha16(got) == row["sha16"], row["name"]
+        if k == 0:
+            assert np.array_equal(got, oracle.composite(_solid(*size), objs, pl))
+
+
+def test_placements_mode_lanczos_full_size(gpu, golden_dir):
+    """Direct composite() callers: boxes != cutout size -> Pillow-exact LANCZOS, overlaps, overhang."""
+    from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
+    big = _big(golden_dir)
+    syn = cases.synthetic
+    for name, W, H, n, seed in [("c2_placements_soft", 1920, 1080, 8, 2), ("c3_placements_soft", 3840, 2160, 32, 3)]:
+        size, objs, pl = syn.placements_workload(W, H, n, seed, "soft")
+        atlas = Atlas(objs)
+        out = composite_device(atlas, [SolidCanvas(size, syn.SOLID_BG)], [coerce_placements(atlas, pl)])[0]
+        got = out.cpu().numpy()
+        assert cases.sha16(got) == big[name]["sha16"], name
+        if n == 8:
+            assert np.array_equal(got, oracle.composite(_solid(W, H), objs, pl))
+        stats = gpu.stats()
+        assert stats["resampled_layers"] > 0 and stats["canvas_pixels"] == W * H
+
+
+def test_c4_variants_batch(gpu, golden_dir):
+    """BASELINE.json configs[3] (first 8 variants): mixed canvas sizes in ONE launch."""
+    from image_transformation_amd.compositor import Atlas, SolidCanvas, render_batch
+    big = _big(golden_dir)
+    syn = cases.synthetic
+    objs, variants = syn.c4_workload("binary", n_variants=8)
+    atlas = Atlas(objs)
+    outs = render_batch([v[1] for v in variants], atlas, [SolidCanvas(v[0], syn.SOLID_BG) for v in variants])
+    for v, o in enumerate(outs):
+        row = big[f"c4_variant_{v}"]
+        assert list(o.shape[1::-1]) == row["canvas"]
+        assert cases.sha16(o.cpu().numpy()) == row["sha16"], row["name"]
+
+
+def test_c5_audio_book_8k(gpu, golden_dir):
+    """BASELINE.json configs[4]: audio_book end to end at 7680x4320 -- fill_solid colour, contact
+    sheet size, and the 4 composite iterations (LANCZOS x8/x4 upscales)."""
+    from image_transformation_amd.background_resizing import solid_canvas
+    from image_transformation_amd.compositor import load_object_images, render
+    big = _big(golden_dir)
+    base = os.path.join(cases.BUNDLE_DIR, "audio_book")
+    objects = load_object_images(os.path.join(base, "results.json"))
+    canvas = solid_canvas(os.path.join(base, "background.png"), (7680, 4320))
+    assert canvas.rgba == (38, 73, 115, 255)
+    for it in range(4):
+        row = big[f"c5_audio_book_iter{it}"]
+        out = render({"placements": row["placements"]}, objects, canvas, as_tensor=True)
+        assert cases.sha16(out.cpu().numpy()) == row["sha16"], row["name"]
+
+
+# ------------------------------------------------------------------------------------------ properties at full size
+def test_properties_full_size(gpu):
+    """Size-independent properties at the bench size (4K, 32 objects):
+    - splitting the placement list into two successive composites equals one composite
+      (sequential 8-bit state, compositor.py:12-21);
+    - an empty placement list is the identity on the background;
+    - a layout translated by (dx, dy) on a larger canvas equals the translated image."""
+    import torch
+    from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
+    syn = cases.synthetic
+    (W, H), objs, pl = syn.placements_workload(3840, 2160, 32, 11, "soft", scale_range=(1.0, 1.0))
+    atlas = Atlas(objs)
+    rows = coerce_placements(atlas, pl)
+    solid = SolidCanvas((W, H), syn.SOLID_BG)
+    full = composite_device(atlas, [solid], [rows])[0]
+    first = composite_device(atlas, [solid], [rows[:13]])[0]
+    second = composite_device(atlas, [first], [rows[13:]])[0]
+    assert torch.equal(full, second)
+    ident = composite_device(atlas, [full], [[]])[0]
+    assert torch.equal(ident, full) and ident.data_ptr() != full.data_ptr()
+    dx, dy = 37, 21
+    moved = [(o, x1 + dx, y1 + dy, x2 + dx, y2 + dy) for (o, x1, y1, x2, y2) in rows]
+    wide = composite_device(atlas, [SolidCanvas((W + 64, H + 64), syn.SOLID_BG)], [moved])[0]
+    assert torch.equal(wide[dy:dy + H - 64, dx:dx + W - 64], full[:H - 64, :W - 64])
+    # order matters where soft layers overlap: reversing must change something
+    rev = composite_device(atlas, [solid], [rows[::-1]])[0]
+    assert not torch.equal(rev, full)
+
+
+def test_ragged_and_extreme_shapes(gpu):
+    """1-pixel canvases/objects, widths that are not multiples of 4 or 256, > 64 layers per canvas."""
+    from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
+    rng = np.random.default_rng(99)
+    for (W, H, n) in [(1, 1, 3), (3, 2, 5), (257, 17, 9), (4399, 33, 7), (1023, 1025, 150)]:
+        objs = {i + 1: cases.synthetic.make_cutout(rng, int(rng.integers(1, 90)), int(rng.integers(1, 70)), "soft")
+                for i in range(min(n, 12))}
+        pl = []
+        for k in range(n):
+            oid = int(rng.integers(1, len(objs) + 1))
+            sh, sw = objs[oid].shape[:2]
+            x1, y1 = int(rng.integers(-sw, W + 1)), int(rng.integers(-sh, H + 1))
+            pl.append({"object_id": oid, "box": [x1, y1, x1 + sw, y1 + sh]})
+        bg = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+        import torch
+        atlas = Atlas(objs)
+        out = composite_device(atlas, [torch.from_numpy(bg).to(gpu.torch_device)], [coerce_placements(atlas, pl)])[0]
+        want = oracle.composite(bg, objs, pl)
+        got = out.cpu().numpy()
+        assert np.array_equal(got, want), ((W, H, n), _maxdiff(got, want))
