@@ -34,6 +34,11 @@ __device__ __forceinline__ uint32_t unpremultiply(uint32_t p) {
 
 __device__ __forceinline__ uint32_t clip8(int32_t v) {
     v >>= kPrecisionBits;  // arithmetic shift, like Pillow's clip8 lookup index
+    // hipcc (ROCm 7.2, gfx950) fuses "shift, clamp to 0..255, pack" into v_ashr_pk_u8_i32 and then
+    // ORs the 16-bit result as if the destination's upper half were zero; it is not (the
+    // instruction only writes D[15:0]), which corrupted blue/alpha on the MI355X.  The empty asm
+    // keeps the shift and the clamp apart so the clamp lowers to v_med3_i32.
+    asm volatile("" : "+v"(v));
     return (uint32_t)min(255, max(0, v));
 }
 
