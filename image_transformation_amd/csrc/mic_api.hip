@@ -47,8 +47,13 @@ extern "C" int mic_version(void) { return (1 << 16) | 0; }
 namespace {
 
 constexpr uint32_t kBlobMagic = 0x4143494du;  // "MICA"
-constexpr uint32_t kBlobVersion = 1;
+constexpr uint32_t kBlobVersion = 2;  // v2: >= 16 guard bytes around every cutout
 constexpr size_t kPixelAlign = 256;
+// The composite kernel reads a layer row with one 16-byte load per lane even where the layer edge
+// cuts through the lane's four pixels, i.e. up to 12 bytes before a cutout's first / after its last
+// pixel.  Every image the kernels read (atlas cutouts, resampled layers) therefore sits between
+// guard bands of at least kGuard readable bytes.
+constexpr size_t kGuard = 16;
 constexpr int64_t kMaxDim = 65535;
 
 struct BlobHeader {
@@ -67,14 +72,14 @@ inline size_t header_bytes(int n) { return sizeof(BlobHeader) + sizeof(BlobEntry
 int blob_layout(int n, const int32_t *ids, const int32_t *w, const int32_t *h,
                 std::vector<BlobEntry> *entries, size_t *total) {
     if (n < 0) return fail(MIC_ERR_INVALID, "atlas: negative object count");
-    size_t off = align_up(header_bytes(n), kPixelAlign);
+    size_t off = align_up(header_bytes(n) + kGuard, kPixelAlign);
     const size_t pixels_offset = off;
     if (entries) entries->clear();
     for (int i = 0; i < n; ++i) {
-        if (w[i] <= 0 || h[i] <= 0 || w[i] > kMaxDim || h[i] > kMaxDim)
+        if (w[i] <= 0 || h[i] <= 0 || w[i] > kMaxDim || h[i] > kMaxDim || (int64_t)w[i] * h[i] >= ((int64_t)1 << 31))
             return fail(MIC_ERR_INVALID, "atlas: object %d has invalid size %dx%d", i, w[i], h[i]);
         if (entries) entries->push_back(BlobEntry{ids ? ids[i] : i, w[i], h[i], 0, off, 0});
-        off = align_up(off + (size_t)w[i] * h[i] * 4, kPixelAlign);
+        off = align_up(off + (size_t)w[i] * h[i] * 4 + kGuard, kPixelAlign);
     }
     (void)pixels_offset;
     *total = off;
@@ -289,7 +294,7 @@ extern "C" int mic_atlas_blob_layout(int n, const int32_t *ids, const int32_t *w
     size_t total = 0;
     if (int rc = blob_layout(n, ids, widths, heights, &entries, &total)) return rc;
     if (bytes < header_bytes(n)) return fail(MIC_ERR_INVALID, "mic_atlas_blob_layout: buffer too small");
-    BlobHeader h{kBlobMagic, kBlobVersion, (uint32_t)n, 0, total, align_up(header_bytes(n), kPixelAlign)};
+    BlobHeader h{kBlobMagic, kBlobVersion, (uint32_t)n, 0, total, align_up(header_bytes(n) + kGuard, kPixelAlign)};
     memcpy(blob_host, &h, sizeof h);
     if (n) memcpy(static_cast<char *>(blob_host) + sizeof h, entries.data(), sizeof(BlobEntry) * n);
     for (int i = 0; i < n; ++i) pixel_offsets[i] = entries[i].offset;
@@ -361,8 +366,8 @@ extern "C" int mic_atlas_from_device_blob(mic_ctx *ctx, const void *blob_dev, si
                                sizeof(BlobEntry) * h.n, hipMemcpyDeviceToHost));
     }
     for (const BlobEntry &e : entries) {
-        if (e.w <= 0 || e.h <= 0 || e.w > kMaxDim || e.h > kMaxDim || e.offset % 4 != 0 ||
-            e.offset + (uint64_t)e.w * e.h * 4 > h.total_bytes)
+        if (e.w <= 0 || e.h <= 0 || e.w > kMaxDim || e.h > kMaxDim || e.offset % 4 != 0 || e.offset < kGuard ||
+            e.offset + (uint64_t)e.w * e.h * 4 + kGuard > h.total_bytes)
             return fail(MIC_ERR_FORMAT, "atlas blob: entry for id %d is out of bounds", e.id);
     }
     mic_atlas *a = new (std::nothrow) mic_atlas();
@@ -497,8 +502,8 @@ extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const
     struct Pending { size_t layer; size_t plan; };
     std::vector<Pending> pending;  // layers whose src is an arena offset, patched after ensure_arena
     std::map<std::tuple<uint64_t, int, int, int>, size_t> dedup;  // (atlas uid, entry, w, h) -> plan
-    size_t arena_need = 0;
-    int max_tiles = 0;
+    size_t arena_need = kPixelAlign;  // leading guard band
+    int max_pages = 0;
 
     for (int ji = 0; ji < n_jobs; ++ji) {
         const mic_job &J = jobs[ji];
@@ -516,9 +521,12 @@ extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const
         d.W = J.width;
         d.H = J.height;
         d.layer_begin = (int32_t)dlayers.size();
-        d.tiles_x = (J.width + kTileW - 1) / kTileW;
-        d.tiles_y = (J.height + kTileH - 1) / kTileH;
-        max_tiles = std::max(max_tiles, d.tiles_x * d.tiles_y);
+        if (d.out % 4 != 0 || d.bg % 4 != 0)
+            return fail(MIC_ERR_INVALID, "job %d: canvas pointers must be 4-byte aligned", ji);
+        // 4 KiB pages aligned to absolute address: one workgroup per page (see mic_internal.h)
+        d.px_shift = (int32_t)((d.out & 4095u) / 4);
+        d.n_pages = (int32_t)(((uint64_t)J.width * J.height + d.px_shift + kPagePx - 1) / kPagePx);
+        max_pages = std::max(max_pages, d.n_pages);
         st.canvas_pixels += (uint64_t)J.width * J.height;
 
         for (int pi = 0; pi < J.n_placements; ++pi) {
@@ -539,9 +547,9 @@ extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const
             const int64_t vx0 = std::max<int64_t>(x1, 0), vx1 = std::min<int64_t>(x1 + w, J.width);
             const int64_t vy0 = std::max<int64_t>(y1, 0), vy1 = std::min<int64_t>(y1 + h, J.height);
             if (vx0 >= vx1 || vy0 >= vy1) continue;
-            if (w > kMaxDim || h > kMaxDim)
-                return fail(MIC_ERR_INVALID, "job %d placement %d: box %lldx%lld exceeds %lld", ji, pi,
-                            (long long)w, (long long)h, (long long)kMaxDim);
+            if (w > kMaxDim || h > kMaxDim || w * h >= ((int64_t)1 << 31))
+                return fail(MIC_ERR_INVALID, "job %d placement %d: box %lldx%lld is too large (side <= %lld, "
+                            "area < 2^31 pixels)", ji, pi, (long long)w, (long long)h, (long long)kMaxDim);
             Layer L{};
             L.dx = (int32_t)x1; L.dy = (int32_t)y1; L.w = (int32_t)w; L.h = (int32_t)h;
             st.layer_pixels += (uint64_t)(vx1 - vx0) * (vy1 - vy0);
@@ -562,10 +570,10 @@ extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const
                     rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
                     if (rp.dw != rp.sw && rp.dh != rp.sh) {
                         rp.tmp_off = arena_need;
-                        arena_need = align_up(arena_need + (size_t)rp.dw * rp.sh * 4, kPixelAlign);
+                        arena_need = align_up(arena_need + (size_t)rp.dw * rp.sh * 4 + kGuard, kPixelAlign);
                     }
                     rp.dst_off = arena_need;
-                    arena_need = align_up(arena_need + (size_t)rp.dw * rp.dh * 4, kPixelAlign);
+                    arena_need = align_up(arena_need + (size_t)rp.dw * rp.dh * 4 + kGuard, kPixelAlign);
                     plan_idx = plans.size();
                     plans.push_back(rp);
                     dedup.emplace(key, plan_idx);
@@ -581,6 +589,12 @@ extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const
     if (arena_need > ((size_t)64 << 30))
         return fail(MIC_ERR_NOMEM, "resampled layers of this call need %zu bytes of scratch", arena_need);
     if (int rc = ensure_arena(ctx, arena_need)) return rc;
+    const int pitch = (max_pages + 7) / 8 * 8;
+    // hot jobs first (lean kernel instantiation): W % 4 == 0, 16-byte aligned canvas, opaque solid bg
+    auto is_hot = [](const Job &d) {
+        return d.W % 4 == 0 && d.out % 16 == 0 && d.bg == 0 && (d.bg_rgba >> 24) == 255u;
+    };
+    const int n_hot = (int)(std::stable_partition(djobs.begin(), djobs.end(), is_hot) - djobs.begin());
     for (const Pending &p : pending)
         dlayers[p.layer].src = reinterpret_cast<uint64_t>(ctx->arena) + plans[p.plan].dst_off;
     PassTables pt;
@@ -613,12 +627,12 @@ extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const
                               pt.max_v_out_h, stream));
     if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
     HIP_TRY(launch_composite(reinterpret_cast<const Job *>(dp + off_jobs),
-                             reinterpret_cast<const Layer *>(dp + off_layers), n_jobs, max_tiles, stream));
+                             reinterpret_cast<const Layer *>(dp + off_layers), n_jobs, n_hot, pitch, stream));
     if (prof) {
         HIP_TRY(hipEventRecord(pe[2], stream));
         ++ctx->prof_calls;
     }
-    st.composite_blocks = (uint64_t)max_tiles * n_jobs;
+    st.composite_blocks = (uint64_t)pitch * n_jobs;
     ctx->stats = st;
     return MIC_OK;
 }

@@ -13,11 +13,19 @@ typedef MIC_GLOBAL uint32_t *gptr;
 typedef const MIC_GLOBAL int32_t *gciptr;
 
 // ---- composite ---------------------------------------------------------------------------
-constexpr int kLaneNPx = 4;                  // pixels per lane per row (16 B)
-constexpr int kTileW = 64 * kLaneNPx;        // one wavefront spans 256 px = 1 KiB per row
-constexpr int kRowsPerWave = 4;
-constexpr int kWavesPerBlock = 4;
-constexpr int kTileH = kRowsPerWave * kWavesPerBlock;
+// The canvas is treated as a linear stream of pixels cut into 4 KiB pages ALIGNED TO ABSOLUTE
+// ADDRESS; one workgroup writes exactly one page.  Measured on MI355X (scripts/streambench.hip,
+// 531 MB): a store stream reaches 6.7-6.8 TB/s only when every workgroup, taken in dispatch
+// order, writes one whole 4 KiB page -- workgroups are dealt round-robin over the 8 XCDs, so each
+// XCD then keeps writing one fixed residue class of pages mod 8.  2-D tiles (256 px x 4 rows per
+// wave: 5.5 TB/s), fatter workgroups (8-16 KiB: 6.0), XCD-contiguous ranges (5.0) and grid-stride
+// persistent loops (4.4) all lose; page offset and read-side placement/alignment do not matter.
+// The composite kernel uses one wavefront per page (16 px per lane) so that the per-page work
+// (one division, layer culling, record broadcast) is amortised over 4 KiB.
+constexpr int kLaneNPx = 4;                    // adjacent pixels per lane per group (16 B)
+constexpr int kWavePx = 64 * kLaneNPx;         // 256 px = 1 KiB per wave-wide access
+constexpr int kGroups = 4;                     // groups per lane, 1 KiB apart
+constexpr int kPagePx = kWavePx * kGroups;     // 1024 px = 4 KiB per workgroup
 
 // One resolved placement: where the layer's pixels live and where they land on the canvas.
 struct alignas(16) Layer {
@@ -35,7 +43,8 @@ struct alignas(16) Job {
     uint32_t bg_rgba;  // solid colour, little-endian r | g<<8 | b<<16 | a<<24
     int32_t W, H;
     int32_t layer_begin, layer_count;
-    int32_t tiles_x, tiles_y;
+    int32_t px_shift;  // pixels of the canvas' first 4 KiB page that precede the canvas: (out % 4096) / 4
+    int32_t n_pages;   // ceil((W*H + px_shift) / 1024)
     int32_t pad0;
 };
 static_assert(sizeof(Job) == 48, "Job layout");
@@ -63,8 +72,10 @@ struct alignas(16) RsJob {
 static_assert(sizeof(RsJob) == 64, "RsJob layout");
 
 // ---- launchers (defined next to their kernels) -----------------------------------------------
-hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_jobs,
-                            int max_tiles, hipStream_t stream);
+// Jobs [0, n_hot) are "hot" (W % 4 == 0, canvas 16-byte aligned, solid opaque background), the
+// rest take the general kernel instantiation.  pitch = max pages per job rounded up to 8.
+hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_jobs, int n_hot,
+                            int pitch, hipStream_t stream);
 hipError_t launch_resample_h(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_rows,
                              hipStream_t stream);
 hipError_t launch_resample_v(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_out_h,
