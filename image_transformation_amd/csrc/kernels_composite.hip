@@ -82,16 +82,20 @@ __device__ __forceinline__ void store1(gptr p, uint32_t v) { __builtin_nontempor
 
 // Does layer rect [dx, dx+w) x [dy, dy+h) touch any pixel of the linear run [a, b] (inclusive)
 // of a canvas W pixels wide?  (ra, ca) / (rb, cb) are the row/column of a and b.
+//
+// Written with the sign-bit trick -- a set of conditions "v_k >= 0" holds iff (v_1 | v_2 | ...) >= 0,
+// and at least one of several such sets holds iff the AND of their OR-words is >= 0 -- so that the
+// whole test is a dozen vector integer ops and ONE compare.  The obvious boolean form compiles to
+// lane-mask arithmetic on the scalar unit (one per CU), which was this kernel's busiest resource.
 __device__ __forceinline__ bool run_hits(int ra, int ca, int rb, int cb, int W, int dx, int dy, int w,
                                          int h) {
-    // branch-free on purpose: this runs for every (lane = layer, group) pair of every page
-    const int x1 = dx + w, y1 = dy + h;  // exclusive
-    const bool same = ra == rb;          // wave-uniform
-    const bool in_a = (dy <= ra) & (ra < y1), in_b = (dy <= rb) & (rb < y1);
-    const bool head = in_a & (x1 > ca) & (same ? dx <= cb : true);  // first row: columns ca..(cb | W-1)
-    const bool tail = !same & in_b & (dx <= cb);                    // last row: columns 0..cb
-    const bool mid = !same & (max(ra + 1, dy) <= min(rb - 1, y1 - 1));  // a full row in between
-    return (dx < W) & (x1 > 0) & (head | tail | mid);
+    const int x1 = dx + w - 1, y1 = dy + h - 1;  // inclusive
+    if (ra == rb)                                // wave-uniform
+        return ((ra - dy) | (y1 - ra) | (cb - dx) | (x1 - ca)) >= 0;
+    const int head = (ra - dy) | (y1 - ra) | (x1 - ca) | (W - 1 - dx);  // first row: columns ca..W-1
+    const int tail = (rb - dy) | (y1 - rb) | (cb - dx) | x1;            // last row: columns 0..cb
+    const int mid = (min(rb - 1, y1) - max(ra + 1, dy)) | x1 | (W - 1 - dx);  // a full row in between
+    return (head & tail & mid) >= 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -115,26 +119,25 @@ struct Group {
 // four groups issue back to back with no divergent branch -- conditional loads made hipcc drain
 // vmcnt between groups, one HBM round trip after another.
 struct Tap {
-    int off;         // < 2^31: the host rejects layers of 2^31 pixels or more
-    int sx;          // layer column under pixel 0
-    bool covered;
-    bool has_layer;  // the group really has a layer this round (wave-uniform)
+    int off;  // pixel offset from L.src (< 2^31: the host rejects layers of 2^31 pixels or more)
+    int sx;   // layer column under pixel 0; -kLaneNPx when this lane does not read the layer
 };
 
-__device__ __forceinline__ Tap tap_regular(const Layer &L, const Group &G) {
+__device__ __forceinline__ Tap tap_regular(const Layer &L, const Group &G, bool has_layer) {
+    const int sy = G.y - L.dy, sx = G.x - L.dx;
+    // covered <=> 0 <= sy < h and -4 < sx < w (sign-bit trick, see run_hits)
+    const bool covered = has_layer && G.regular && ((sy | (L.h - 1 - sy) | (sx + kLaneNPx - 1) | (L.w - 1 - sx)) >= 0);
     Tap t;
-    const int sy = G.y - L.dy;
-    t.sx = G.x - L.dx;
-    t.covered = G.regular && sy >= 0 && sy < L.h && t.sx > -kLaneNPx && t.sx < L.w;
-    t.off = t.covered ? sy * L.w + t.sx : 0;
-    t.has_layer = true;
+    t.off = covered ? sy * L.w + sx : 0;
+    t.sx = covered ? sx : -kLaneNPx;
     return t;
 }
 
+// Keep the loaded pixels that lie inside the layer row, zero (transparent) the rest.
 __device__ __forceinline__ u32x4 mask_tap(const Tap &t, const Layer &L, u32x4 v) {
     u32x4 s;
 #pragma unroll
-    for (int j = 0; j < kLaneNPx; ++j) s[j] = (t.covered && (uint32_t)(t.sx + j) < (uint32_t)L.w) ? v[j] : 0u;
+    for (int j = 0; j < kLaneNPx; ++j) s[j] = (uint32_t)(t.sx + j) < (uint32_t)L.w ? v[j] : 0u;
     return s;
 }
 
@@ -159,11 +162,13 @@ __device__ __forceinline__ u32x4 fetch_straddler(const Layer &L, const Group &G,
     return s;
 }
 
+// (launch bounds: hipcc settles for 85 VGPRs = 5 waves/SIMD unless told that 7 are wanted; 70 VGPRs,
+// no spills.  8 waves would spill.)
 // HOT = jobs with W % 4 == 0, a 16-byte aligned canvas and a solid opaque background (what the
 // reference's pipeline produces: fill_solid canvases, background_resizing.py:32); every other job
 // (odd widths, background images, translucent colours) takes the general instantiation.
 template <bool HOT>
-__global__ __launch_bounds__(64) void composite_kernel(const Job *__restrict__ jobs,
+__global__ __launch_bounds__(64, HOT ? 7 : 1) void composite_kernel(const Job *__restrict__ jobs,
                                                        const Layer *__restrict__ layers) {
     const Job job = jobs[blockIdx.y];
     if ((int)blockIdx.x >= job.n_pages) return;
@@ -331,6 +336,7 @@ __global__ __launch_bounds__(64) void composite_kernel(const Job *__restrict__ j
             u32x4 s[kGroups];
             Layer L[kGroups];
             Tap tap[kGroups];
+            bool has_layer[kGroups];
 #pragma unroll
             for (int r = 0; r < kGroups; ++r) {  // issue: one 16-byte load per lane per group
                 const bool has = m[r] != 0;
@@ -343,11 +349,14 @@ __global__ __launch_bounds__(64) void composite_kernel(const Job *__restrict__ j
                 L[r].dy = __builtin_amdgcn_readlane(mine.dy, i);
                 L[r].w = __builtin_amdgcn_readlane(mine.w, i);
                 L[r].h = __builtin_amdgcn_readlane(mine.h, i);
-                tap[r] = tap_regular(L[r], G[r]);
-                tap[r].has_layer = has;
-                tap[r].covered = tap[r].covered && has;
-                tap[r].off = tap[r].covered ? tap[r].off : 0;
-                s[r] = load4(reinterpret_cast<gcptr>(L[r].src) + tap[r].off);
+                has_layer[r] = has;
+                tap[r] = tap_regular(L[r], G[r], has);
+                // uniform base (SGPR pair) + unsigned 32-bit lane offset -> the `saddr` form of
+                // global_load: no 64-bit address in vector registers.  The 16-byte bias keeps the
+                // offset non-negative when the load starts in the guard band before the cutout.
+                const MIC_GLOBAL char *basep = reinterpret_cast<const MIC_GLOBAL char *>(L[r].src) - 16;
+                s[r] = __builtin_nontemporal_load(
+                    reinterpret_cast<const MIC_GLOBAL u32x4_a4 *>(basep + (uint32_t)(tap[r].off * 4 + 16)));
             }
 #pragma unroll
             for (int r = 0; r < kGroups; ++r) {  // consume
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(64) void composite_kernel(const Job *__restrict__ j
                 if (!ALIGNED) {
                     if (__any(!G[r].regular) && L[r].w > 0) {
                         const u32x4 t = fetch_straddler(L[r], G[r], W);
-                        if (!G[r].regular && tap[r].has_layer) s[r] = t;
+                        if (!G[r].regular && has_layer[r]) s[r] = t;
                     }
                 }
             }
