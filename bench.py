@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(objs, placements, size, budget_s=10.0, max_reps=50):
+def cpu_baseline(objs, placements, size, budget_s=12.0, max_reps=5000):
     """The CPU oracle ("port" of the reference's Pillow path, 1 thread) on the same workload:
     bounded sample of whole-canvas composites of layout 0."""
     import numpy as np
@@ -119,7 +119,7 @@ def main():
     for k in range(args.warmup):
         plan.run(out_sets[k % n_sets])
     torch.cuda.synchronize()
-    stats = ctx.stats()
+    stats = plan.stats()
 
     # ---- timed region: exactly K steps ----
     ctx.profile_begin(args.steps)
@@ -127,7 +127,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        plan.run(out_sets[k % n_sets])
+        plan.run(out_sets[k % n_sets], check=False)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -177,7 +177,7 @@ def main():
         torch.cuda.synchronize()
         e1 = time.perf_counter() - t0
         n1, c1, _ = ctx.profile_end()
-        s1 = ctx.stats()
+        s1 = one.stats()
         result["single_canvas"] = {"ms_per_canvas_wall": round(e1 / 100 * 1e3, 4), "kernel_ms": round(c1 / n1, 4),
                                    "Mpixels_per_s": round(W * H * 100 / e1 / 1e6, 1),
                                    "roofline_frac": round((4 * s1["canvas_pixels"] + 4 * s1["layer_pixels"]) /

@@ -70,6 +70,11 @@ SYMBOLS = {
     "mic_atlas_destroy": (ctypes.c_int, [_P]),
     "mic_composite_batch": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(_P), ctypes.c_int,
                                            ctypes.POINTER(Job), ctypes.c_int, _P]),
+    "mic_plan_create": (ctypes.c_int, [_P, ctypes.c_int, ctypes.POINTER(_P), ctypes.c_int, ctypes.POINTER(Job),
+                                       ctypes.c_int, ctypes.POINTER(_P)]),
+    "mic_plan_run": (ctypes.c_int, [_P, ctypes.POINTER(_P), _P]),
+    "mic_plan_destroy": (ctypes.c_int, [_P]),
+    "mic_plan_stats": (ctypes.c_int, [_P, ctypes.POINTER(Stats)]),
     "mic_resize": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
                                   ctypes.c_int, _P]),
     "mic_median_rgb": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8), _P]),

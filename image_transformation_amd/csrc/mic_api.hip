@@ -15,7 +15,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/mic.h"
+#include "../../include/mic.h"  // declares mic_plan, mic_ctx, mic_atlas
 #include "mic_internal.h"
 #include "resample_coeffs.h"
 
@@ -431,8 +431,8 @@ struct PassTables {
     int max_h_out_w = 0, max_h_rows = 0, max_v_out_w = 0, max_v_out_h = 0;
 };
 
-int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, PassTables *pt) {
-    const uint64_t arena = reinterpret_cast<uint64_t>(ctx->arena);
+int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, void *scratch, PassTables *pt) {
+    const uint64_t arena = reinterpret_cast<uint64_t>(scratch);
     for (const ResizePlan &p : plans) {
         const bool need_h = p.dw != p.sw, need_v = p.dh != p.sh;
         const uint64_t dst = p.dst_ptr ? p.dst_ptr : arena + p.dst_off;
@@ -477,40 +477,59 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
 }  // namespace
 
 // ------------------------------------------------------------------------------------ composite
-extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,
-                                   const mic_job *jobs, int filter, void *stream_v) {
-    if (int rc = ctx_enter(ctx)) return rc;
-    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+// A plan = the resolved form of a batch of jobs: device layer records, resample pass tables and
+// scratch for resampled layers.  mic_composite_batch builds a transient one on the context's
+// arena/staging ring; mic_plan_create builds a persistent one that owns its device memory, so
+// that re-running it (mic_plan_run) only uploads the small job table (output pointers) and
+// launches.  Pixel work is redone on every run -- nothing is cached but addresses.
+struct mic_plan {
+    mic_ctx *ctx = nullptr;
+    int filter = 0;
+    bool persistent = false;
+    std::vector<Job> jobs;     // caller order; out / px_shift / n_pages are set per run
+    std::vector<Job> ordered;  // hot jobs first, rebuilt per run
+    std::vector<Layer> layers;
+    PassTables pt;
+    void *scratch = nullptr;   // resampled layers (persistent plans own it; transient ones borrow ctx->arena)
+    size_t scratch_bytes = 0;
+    void *tables_dev = nullptr;  // persistent plans: jobs | layers | h passes | v passes
+    size_t off_layers = 0, off_h = 0, off_v = 0, total = 0;
+    mic_stats stats{};
+};
+
+static void plan_offsets(mic_plan *P) {
+    P->off_layers = align_up(sizeof(Job) * P->jobs.size(), 64);
+    P->off_h = align_up(P->off_layers + sizeof(Layer) * P->layers.size(), 64);
+    P->off_v = align_up(P->off_h + sizeof(RsJob) * P->pt.h.size(), 64);
+    P->total = align_up(P->off_v + sizeof(RsJob) * P->pt.v.size(), 64);
+}
+
+static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs, const mic_job *jobs,
+                      int filter, bool persistent, mic_plan *P) {
     if (n_jobs < 0 || n_atlases < 0 || (n_jobs > 0 && !jobs) || (n_atlases > 0 && !atlases))
-        return fail(MIC_ERR_INVALID, "mic_composite_batch: bad arguments");
+        return fail(MIC_ERR_INVALID, "composite: bad arguments");
     if (filter != MIC_FILTER_LANCZOS && filter != MIC_FILTER_BILINEAR)
         return fail(MIC_ERR_INVALID, "unknown filter %d", filter);
     if (n_jobs > 65535) return fail(MIC_ERR_INVALID, "at most 65535 jobs per call");
     for (int a = 0; a < n_atlases; ++a)
         if (!atlases[a] || atlases[a]->ctx != ctx)
             return fail(MIC_ERR_INVALID, "atlas %d is null or belongs to another context", a);
-    if (int rc = adopt_stream(ctx, stream)) return rc;
+    P->ctx = ctx;
+    P->filter = filter;
+    P->persistent = persistent;
+    P->jobs.assign((size_t)n_jobs, Job{});
     mic_stats st{};
-    if (n_jobs == 0) {
-        ctx->stats = st;
-        return MIC_OK;
-    }
 
-    std::vector<Job> djobs((size_t)n_jobs);
-    std::vector<Layer> dlayers;
     std::vector<ResizePlan> plans;
     struct Pending { size_t layer; size_t plan; };
-    std::vector<Pending> pending;  // layers whose src is an arena offset, patched after ensure_arena
+    std::vector<Pending> pending;  // layers whose src is a scratch offset, patched once scratch exists
     std::map<std::tuple<uint64_t, int, int, int>, size_t> dedup;  // (atlas uid, entry, w, h) -> plan
-    size_t arena_need = kPixelAlign;  // leading guard band
-    int max_pages = 0;
+    size_t scratch_need = kPixelAlign;  // leading guard band
 
     for (int ji = 0; ji < n_jobs; ++ji) {
         const mic_job &J = jobs[ji];
         if (J.width <= 0 || J.height <= 0 || J.width > kMaxDim || J.height > kMaxDim)
             return fail(MIC_ERR_INVALID, "job %d: invalid canvas size %dx%d", ji, J.width, J.height);
-        if (!J.out_dev) return fail(MIC_ERR_INVALID, "job %d: null output canvas", ji);
-        if (J.out_dev == J.bg_dev) return fail(MIC_ERR_INVALID, "job %d: output aliases the background", ji);
         if (J.n_placements < 0 || (J.n_placements > 0 && !J.placements))
             return fail(MIC_ERR_INVALID, "job %d: bad placement list", ji);
         Job d{};
@@ -520,29 +539,24 @@ extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const
                     ((uint32_t)J.bg_rgba[3] << 24);
         d.W = J.width;
         d.H = J.height;
-        d.layer_begin = (int32_t)dlayers.size();
-        if (d.out % 4 != 0 || d.bg % 4 != 0)
-            return fail(MIC_ERR_INVALID, "job %d: canvas pointers must be 4-byte aligned", ji);
-        // 4 KiB pages aligned to absolute address: one workgroup per page (see mic_internal.h)
-        d.px_shift = (int32_t)((d.out & 4095u) / 4);
-        d.n_pages = (int32_t)(((uint64_t)J.width * J.height + d.px_shift + kPagePx - 1) / kPagePx);
-        max_pages = std::max(max_pages, d.n_pages);
+        d.layer_begin = (int32_t)P->layers.size();
+        if (d.bg % 4 != 0) return fail(MIC_ERR_INVALID, "job %d: canvas pointers must be 4-byte aligned", ji);
         st.canvas_pixels += (uint64_t)J.width * J.height;
 
         for (int pi = 0; pi < J.n_placements; ++pi) {
-            const mic_placement &P = J.placements[pi];
-            if (P.atlas < 0 || P.atlas >= n_atlases)
-                return fail(MIC_ERR_INVALID, "job %d placement %d: atlas index %d out of range", ji, pi, P.atlas);
-            const mic_atlas *A = atlases[P.atlas];
-            auto it = A->index.find(P.object_id);
+            const mic_placement &Pl = J.placements[pi];
+            if (Pl.atlas < 0 || Pl.atlas >= n_atlases)
+                return fail(MIC_ERR_INVALID, "job %d placement %d: atlas index %d out of range", ji, pi, Pl.atlas);
+            const mic_atlas *A = atlases[Pl.atlas];
+            auto it = A->index.find(Pl.object_id);
             if (it == A->index.end()) {  // compositor.py:14-15
                 ++st.skipped_placements;
                 continue;
             }
             const BlobEntry &E = A->entries[it->second];
-            const int64_t x1 = P.box[0], y1 = P.box[1];
-            const int64_t w = std::max<int64_t>(1, (int64_t)P.box[2] - x1);
-            const int64_t h = std::max<int64_t>(1, (int64_t)P.box[3] - y1);
+            const int64_t x1 = Pl.box[0], y1 = Pl.box[1];
+            const int64_t w = std::max<int64_t>(1, (int64_t)Pl.box[2] - x1);
+            const int64_t h = std::max<int64_t>(1, (int64_t)Pl.box[3] - y1);
             // in-canvas part of the layer; layers that miss the canvas have no effect at all
             const int64_t vx0 = std::max<int64_t>(x1, 0), vx1 = std::min<int64_t>(x1 + w, J.width);
             const int64_t vy0 = std::max<int64_t>(y1, 0), vy1 = std::min<int64_t>(y1 + h, J.height);
@@ -569,71 +583,168 @@ extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const
                     rp.src = reinterpret_cast<uint64_t>(A->blob) + E.offset;
                     rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
                     if (rp.dw != rp.sw && rp.dh != rp.sh) {
-                        rp.tmp_off = arena_need;
-                        arena_need = align_up(arena_need + (size_t)rp.dw * rp.sh * 4 + kGuard, kPixelAlign);
+                        rp.tmp_off = scratch_need;
+                        scratch_need = align_up(scratch_need + (size_t)rp.dw * rp.sh * 4 + kGuard, kPixelAlign);
                     }
-                    rp.dst_off = arena_need;
-                    arena_need = align_up(arena_need + (size_t)rp.dw * rp.dh * 4 + kGuard, kPixelAlign);
+                    rp.dst_off = scratch_need;
+                    scratch_need = align_up(scratch_need + (size_t)rp.dw * rp.dh * 4 + kGuard, kPixelAlign);
                     plan_idx = plans.size();
                     plans.push_back(rp);
                     dedup.emplace(key, plan_idx);
                 }
-                pending.push_back({dlayers.size(), plan_idx});
+                pending.push_back({P->layers.size(), plan_idx});
             }
-            dlayers.push_back(L);
+            P->layers.push_back(L);
         }
-        d.layer_count = (int32_t)dlayers.size() - d.layer_begin;
-        djobs[(size_t)ji] = d;
+        d.layer_count = (int32_t)P->layers.size() - d.layer_begin;
+        P->jobs[(size_t)ji] = d;
     }
+    P->stats = st;
 
-    if (arena_need > ((size_t)64 << 30))
-        return fail(MIC_ERR_NOMEM, "resampled layers of this call need %zu bytes of scratch", arena_need);
-    if (int rc = ensure_arena(ctx, arena_need)) return rc;
+    if (scratch_need > ((size_t)64 << 30))
+        return fail(MIC_ERR_NOMEM, "resampled layers of this call need %zu bytes of scratch", scratch_need);
+    void *scratch = nullptr;
+    if (plans.empty()) {
+        scratch_need = 0;
+    } else if (persistent) {
+        HIP_TRY(hipMalloc(&P->scratch, scratch_need));
+        P->scratch_bytes = scratch_need;
+        scratch = P->scratch;
+    } else {
+        if (int rc = ensure_arena(ctx, scratch_need)) return rc;
+        scratch = ctx->arena;
+    }
+    for (const Pending &pd : pending)
+        P->layers[pd.layer].src = reinterpret_cast<uint64_t>(scratch) + plans[pd.plan].dst_off;
+    if (int rc = plan_passes(ctx, plans, filter, scratch, &P->pt)) return rc;
+    plan_offsets(P);
+    if (persistent && P->total > 0) {
+        HIP_TRY(hipMalloc(&P->tables_dev, P->total));
+        if (!P->layers.empty())
+            HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_layers, P->layers.data(),
+                              sizeof(Layer) * P->layers.size(), hipMemcpyHostToDevice));
+        if (!P->pt.h.empty())
+            HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_h, P->pt.h.data(),
+                              sizeof(RsJob) * P->pt.h.size(), hipMemcpyHostToDevice));
+        if (!P->pt.v.empty())
+            HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_v, P->pt.v.data(),
+                              sizeof(RsJob) * P->pt.v.size(), hipMemcpyHostToDevice));
+    }
+    return MIC_OK;
+}
+
+static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
+    mic_ctx *ctx = P->ctx;
+    const int n_jobs = (int)P->jobs.size();
+    if (n_jobs == 0) {
+        ctx->stats = P->stats;
+        return MIC_OK;
+    }
+    if (int rc = adopt_stream(ctx, stream)) return rc;
+    int max_pages = 0;
+    for (int ji = 0; ji < n_jobs; ++ji) {
+        Job &d = P->jobs[(size_t)ji];
+        if (outs) d.out = reinterpret_cast<uint64_t>(outs[ji]);
+        if (!d.out) return fail(MIC_ERR_INVALID, "job %d: null output canvas", ji);
+        if (d.out == d.bg) return fail(MIC_ERR_INVALID, "job %d: output aliases the background", ji);
+        if (d.out % 4 != 0) return fail(MIC_ERR_INVALID, "job %d: canvas pointers must be 4-byte aligned", ji);
+        // 4 KiB pages aligned to absolute address: one workgroup per page (see mic_internal.h)
+        d.px_shift = (int32_t)((d.out & 4095u) / 4);
+        d.n_pages = (int32_t)(((uint64_t)d.W * d.H + d.px_shift + kPagePx - 1) / kPagePx);
+        max_pages = std::max(max_pages, d.n_pages);
+    }
     const int pitch = (max_pages + 7) / 8 * 8;
     // hot jobs first (lean kernel instantiation): W % 4 == 0, 16-byte aligned canvas, opaque solid bg
     auto is_hot = [](const Job &d) {
         return d.W % 4 == 0 && d.out % 16 == 0 && d.bg == 0 && (d.bg_rgba >> 24) == 255u;
     };
-    const int n_hot = (int)(std::stable_partition(djobs.begin(), djobs.end(), is_hot) - djobs.begin());
-    for (const Pending &p : pending)
-        dlayers[p.layer].src = reinterpret_cast<uint64_t>(ctx->arena) + plans[p.plan].dst_off;
-    PassTables pt;
-    if (int rc = plan_passes(ctx, plans, filter, &pt)) return rc;
+    P->ordered = P->jobs;
+    const int n_hot = (int)(std::stable_partition(P->ordered.begin(), P->ordered.end(), is_hot) - P->ordered.begin());
 
-    // ---- one params blob: jobs | layers | horizontal passes | vertical passes ----
-    const size_t off_jobs = 0;
-    const size_t off_layers = align_up(off_jobs + sizeof(Job) * djobs.size(), 64);
-    const size_t off_h = align_up(off_layers + sizeof(Layer) * dlayers.size(), 64);
-    const size_t off_v = align_up(off_h + sizeof(RsJob) * pt.h.size(), 64);
-    const size_t total = align_up(off_v + sizeof(RsJob) * pt.v.size(), 64);
+    // the job table always travels (output pointers change per run); the rest only for transient plans
+    const size_t upload = P->persistent ? sizeof(Job) * P->ordered.size() : P->total;
     Slot *slot = nullptr;
-    if (int rc = acquire_slot(ctx, total, &slot)) return rc;
+    if (int rc = acquire_slot(ctx, upload, &slot)) return rc;
     char *hp = static_cast<char *>(slot->host);
-    memcpy(hp + off_jobs, djobs.data(), sizeof(Job) * djobs.size());
-    if (!dlayers.empty()) memcpy(hp + off_layers, dlayers.data(), sizeof(Layer) * dlayers.size());
-    if (!pt.h.empty()) memcpy(hp + off_h, pt.h.data(), sizeof(RsJob) * pt.h.size());
-    if (!pt.v.empty()) memcpy(hp + off_v, pt.v.data(), sizeof(RsJob) * pt.v.size());
-    HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, total, hipMemcpyHostToDevice, stream));
+    memcpy(hp, P->ordered.data(), sizeof(Job) * P->ordered.size());
+    char *dp;
+    if (P->persistent) {
+        dp = static_cast<char *>(P->tables_dev);
+    } else {
+        dp = static_cast<char *>(slot->dev);
+        if (!P->layers.empty()) memcpy(hp + P->off_layers, P->layers.data(), sizeof(Layer) * P->layers.size());
+        if (!P->pt.h.empty()) memcpy(hp + P->off_h, P->pt.h.data(), sizeof(RsJob) * P->pt.h.size());
+        if (!P->pt.v.empty()) memcpy(hp + P->off_v, P->pt.v.data(), sizeof(RsJob) * P->pt.v.size());
+    }
+    HIP_TRY(hipMemcpyAsync(dp, slot->host, upload, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(slot->ev, stream));
     slot->pending = true;
 
-    char *dp = static_cast<char *>(slot->dev);
     const bool prof = ctx->profiling && ctx->prof_calls < ctx->prof_max;
     hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], stream));
-    HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + off_h), (int)pt.h.size(), pt.max_h_out_w,
-                              pt.max_h_rows, stream));
-    HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + off_v), (int)pt.v.size(), pt.max_v_out_w,
-                              pt.max_v_out_h, stream));
+    HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + P->off_h), (int)P->pt.h.size(),
+                              P->pt.max_h_out_w, P->pt.max_h_rows, stream));
+    HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + P->off_v), (int)P->pt.v.size(),
+                              P->pt.max_v_out_w, P->pt.max_v_out_h, stream));
     if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
-    HIP_TRY(launch_composite(reinterpret_cast<const Job *>(dp + off_jobs),
-                             reinterpret_cast<const Layer *>(dp + off_layers), n_jobs, n_hot, pitch, stream));
+    HIP_TRY(launch_composite(reinterpret_cast<const Job *>(dp), reinterpret_cast<const Layer *>(dp + P->off_layers),
+                             n_jobs, n_hot, pitch, stream));
     if (prof) {
         HIP_TRY(hipEventRecord(pe[2], stream));
         ++ctx->prof_calls;
     }
-    st.composite_blocks = (uint64_t)pitch * n_jobs;
-    ctx->stats = st;
+    P->stats.composite_blocks = (uint64_t)pitch * n_jobs;
+    ctx->stats = P->stats;
+    return MIC_OK;
+}
+
+extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,
+                                   const mic_job *jobs, int filter, void *stream_v) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (int rc = adopt_stream(ctx, stream)) return rc;  // before the transient plan may regrow the arena
+    mic_plan P;
+    if (int rc = plan_build(ctx, n_atlases, atlases, n_jobs, jobs, filter, /*persistent=*/false, &P)) return rc;
+    return plan_submit(&P, nullptr, stream);
+}
+
+extern "C" int mic_plan_create(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,
+                               const mic_job *jobs, int filter, mic_plan **out) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    if (!out) return fail(MIC_ERR_INVALID, "mic_plan_create: null out");
+    *out = nullptr;
+    mic_plan *P = new (std::nothrow) mic_plan();
+    if (!P) return fail(MIC_ERR_NOMEM, "out of host memory");
+    if (int rc = plan_build(ctx, n_atlases, atlases, n_jobs, jobs, filter, /*persistent=*/true, P)) {
+        mic_plan_destroy(P);
+        return rc;
+    }
+    *out = P;
+    return MIC_OK;
+}
+
+extern "C" int mic_plan_run(mic_plan *plan, void *const *outs, void *stream) {
+    if (!plan) return fail(MIC_ERR_INVALID, "mic_plan_run: null plan");
+    if (int rc = ctx_enter(plan->ctx)) return rc;
+    return plan_submit(plan, outs, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mic_plan_destroy(mic_plan *plan) {
+    if (!plan) return MIC_OK;
+    if (plan->ctx) {
+        (void)hipSetDevice(plan->ctx->device);
+        if (plan->scratch || plan->tables_dev) (void)hipDeviceSynchronize();
+    }
+    if (plan->scratch) (void)hipFree(plan->scratch);
+    if (plan->tables_dev) (void)hipFree(plan->tables_dev);
+    delete plan;
+    return MIC_OK;
+}
+
+extern "C" int mic_plan_stats(const mic_plan *plan, mic_stats *out) {
+    if (!plan || !out) return fail(MIC_ERR_INVALID, "mic_plan_stats: null argument");
+    *out = plan->stats;
     return MIC_OK;
 }
 
@@ -701,7 +812,7 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
     if (int rc = ensure_arena(ctx, need)) return rc;
     PassTables pt;
     std::vector<ResizePlan> plans{rp};
-    if (int rc = plan_passes(ctx, plans, filter, &pt)) return rc;
+    if (int rc = plan_passes(ctx, plans, filter, ctx->arena, &pt)) return rc;
     const size_t off_v = 64;
     Slot *slot = nullptr;
     if (int rc = acquire_slot(ctx, 128, &slot)) return rc;

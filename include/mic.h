@@ -33,6 +33,7 @@ extern "C" {
 
 typedef struct mic_ctx mic_ctx;     /* per-process, per-device state (tables, scratch arena) */
 typedef struct mic_atlas mic_atlas; /* device-resident packed cutouts + id/size table        */
+typedef struct mic_plan mic_plan;   /* a resolved batch of composite jobs, re-runnable            */
 
 enum mic_status {
     MIC_OK = 0,
@@ -73,7 +74,7 @@ int mic_atlas_blob_layout(int n, const int32_t *ids, const int32_t *widths, cons
                           void *blob_host, size_t bytes, uint64_t *pixel_offsets);
 /* Wrap a device blob (layout above; e.g. received by an RCCL broadcast).  The atlas does not
  * own the memory: the caller keeps it alive until mic_atlas_destroy.  `header_host` may pass
- * the first mic_atlas_header_bytes(n) bytes of the blob if the caller has them on the host,
+ * the first 32 + 32*n bytes of the blob (header + table) if the caller has them on the host,
  * otherwise NULL and the header is read back from the device.                              */
 int mic_atlas_from_device_blob(mic_ctx *ctx, const void *blob_dev, size_t bytes,
                                const void *header_host, mic_atlas **out);
@@ -111,6 +112,19 @@ typedef struct mic_job {
 int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,
                         const mic_job *jobs, int filter, void *stream);
 
+/* The same batch, resolved once: mic_plan_create does what mic_composite_batch does before its
+ * launches (placement -> device layer records, resample tables, scratch for resampled layers,
+ * all owned by the plan) and mic_plan_run re-executes ALL the pixel work -- only addresses are
+ * kept, never pixels -- writing canvas i to outs[i] (or to the jobs' own out_dev if outs is NULL;
+ * out_dev may be NULL at creation when outs will be given).  This is what the refine loop of
+ * run_macro_only (macro_placement_test.py:1523-1703) or a batch renderer calls per iteration:
+ * per run the host cost is one small job-table upload and the launches.  The atlases must outlive
+ * the plan.                                                                                    */
+int mic_plan_create(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,
+                    const mic_job *jobs, int filter, mic_plan **out);
+int mic_plan_run(mic_plan *plan, void *const *outs, void *stream);
+int mic_plan_destroy(mic_plan *plan);
+
 /* Image.resize((out_w,out_h), filter) of one device RGBA image (compositor.py:20 call shape;
  * also the thumbnail resample of macro_placement_test.py:194).                             */
 int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int32_t src_h, void *dst_dev,
@@ -144,6 +158,7 @@ typedef struct mic_stats {
     uint64_t composite_blocks;    /* workgroups launched by the composite kernel           */
 } mic_stats;
 int mic_last_stats(const mic_ctx *ctx, mic_stats *out);
+int mic_plan_stats(const mic_plan *plan, mic_stats *out);
 
 /* Kernel timing with HIP events recorded on the launch stream, for bench.py's roofline: between
  * mic_profile_begin and mic_profile_end every mic_composite_batch call brackets its composite
