@@ -137,6 +137,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # HBM bytes per launch from the PMC counters: measured separately with rocprofv3 (bench.py cannot
+    # run under --pmc and time itself) and committed under profiles/; only quoted for the workload
+    # it was measured on.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj["workload"] == {"batch": B, "alpha": args.alpha, "canvas": [W, H], "objects": 32}:
+            traffic = tj["per_launch"]["hbm_bytes"]
+
     px_per_step = B * W * H * world
     value = px_per_step * args.steps / elapsed / 1e6
     kernel_ms = comp_ms / max(n_prof, 1)
@@ -154,7 +165,9 @@ def main():
                    "canvases_per_step_per_gpu": B, "alpha": args.alpha, "parallelism": f"variants sharded v mod {world}",
                    "background": "solid, synthesised in-kernel", "filter": "identity scale (Flex pipeline)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                     "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
+                     if traffic else None,
                      "kernel": "composite_kernel", "kernel_ms": round(kernel_ms, 4),
                      "algorithmic_bytes_per_launch": b_alg,
                      "read_frac_of_peak": round(4 * stats["layer_pixels"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)

@@ -1,0 +1,64 @@
+"""Exhaustive checks of the two exact shortcuts the composite kernel takes (kernels_composite.hip):
+
+  * destination alpha 255:  Pillow's AlphaComposite.c formula == div255(s*sa + d*(255-sa) + 128),
+    alpha 255, for every (sa, s, d) in 0..255 (16.7 M triples) -- over_opaque_dst();
+  * source alpha 0 / 255:   the formula keeps dst / takes src exactly, for every destination alpha
+    -- the select path for binary-alpha cutouts;
+  * the packed form (R and B in the two 16-bit halves of one register) never carries.
+
+Pure numpy; pins the identities the HIP code relies on to Pillow's published integer formula
+(restated in oracle/mic_oracle.c and itself pinned against the reference's fixtures)."""
+import numpy as np
+
+
+def _d255(t):
+    return ((t >> 8) + t) >> 8
+
+
+def _pillow(s, sa, d, da):
+    outa255 = sa * 255 + da * (255 - sa)
+    coef1 = np.where(sa > 0, sa * 255 * 255 * 128 // np.maximum(outa255, 1), 0)
+    coef2 = 255 * 128 - coef1
+    c = _d255(s * coef1 + d * coef2 + (0x80 << 7)) >> 7
+    a = _d255(outa255 + 0x80)
+    return np.where(sa == 0, d, c), np.where(sa == 0, da, a)
+
+
+def test_opaque_destination_identity_exhaustive():
+    sa = np.arange(256, dtype=np.int64)[:, None, None]
+    s = np.arange(256, dtype=np.int64)[None, :, None]
+    d = np.arange(256, dtype=np.int64)[None, None, :]
+    c, a = _pillow(s, sa, d, 255)
+    T = s * sa + d * (255 - sa) + 128
+    assert np.array_equal(c, _d255(T))
+    assert (a == 255).all()
+    assert int((T + (T >> 8)).max()) < 65536  # two channels per 32-bit register never carry
+
+
+def test_binary_source_alpha_is_a_select_for_any_destination():
+    s = np.arange(256, dtype=np.int64)[:, None, None]
+    d = np.arange(256, dtype=np.int64)[None, :, None]
+    da = np.arange(256, dtype=np.int64)[None, None, :]
+    c, a = _pillow(s, np.int64(255), d, da)
+    assert (c == s).all() and (a == 255).all()
+    c0, a0 = _pillow(s, np.int64(0), d, da)
+    assert (c0 == d).all() and (a0 == da).all()
+
+
+def test_packed_lanes_match_scalar():
+    rng = np.random.default_rng(0)
+    s = rng.integers(0, 2 ** 32, 200_000, dtype=np.uint64)
+    d = rng.integers(0, 2 ** 32, 200_000, dtype=np.uint64) | 0xFF000000
+    sa, na = s >> 24, 255 - (s >> 24)
+    M = 0x00FF00FF
+    rb = ((s & M) * sa + (d & M) * na + 0x00800080) & 0xFFFFFFFF
+    g = ((s >> 8) & 0xFF) * sa + ((d >> 8) & 0xFF) * na + 0x80
+    rb = ((((rb >> 8) & M) + rb) >> 8) & M
+    g = ((g >> 8) + g) >> 8
+    packed = rb | (g << 8) | 0xFF000000
+    want = np.zeros_like(packed)
+    for sh in (0, 8, 16):
+        c, _ = _pillow((s >> sh) & 255, sa, (d >> sh) & 255, 255)
+        want |= c.astype(np.uint64) << sh
+    want |= 0xFF000000
+    assert np.array_equal(packed, want)
