@@ -102,210 +102,161 @@ __device__ __forceinline__ bool run_hits(int ra, int ca, int rb, int cb, int W, 
 // Composite: one wave per page.
 // ------------------------------------------------------------------------------------------------
 
-// One group of four pixels of a lane: linear indices q .. q+3, of which [lo, hi) lie in the canvas.
-// ALIGNED jobs (W % 4 == 0 and a 16-byte aligned canvas): a group is either wholly inside one
-// canvas row or wholly outside the canvas, so `regular` is the whole story and lo/hi are unused.
+// One group of four pixels of a lane.  Pixels 0..k-1 lie in canvas row y from column x on; when the
+// canvas width is not a multiple of 4 a group can straddle a row end: pixels k..3 then start row
+// y+1 at column 0 (k == 4: no straddle).
 struct Group {
-    int x, y;      // canvas column/row of the group's first in-canvas pixel (pixel `lo`)
-    int lo, hi;    // 0, 4 except at the canvas ends of a page-misaligned canvas
-    bool regular;  // all four pixels inside the canvas and in the same row
+    int x, y, k;
 };
 
-// Where (as a pixel offset from L.src) one group reads layer L, and whether it reads at all.
-// A group that the layer's left/right edge cuts through still issues ONE 16-byte load: it starts
-// up to 3 pixels before the row or ends up to 3 pixels after it (previous/next row, or the guard
-// band every image the kernels read is allocated with) and the stray pixels are masked afterwards.
-// Lanes the layer does not cover read offset 0 (a harmless broadcast) so that the loads of all
-// four groups issue back to back with no divergent branch -- conditional loads made hipcc drain
-// vmcnt between groups, one HBM round trip after another.
+// Where (as a pixel offset from L.src) a group segment reads layer L.  A segment that the layer's
+// left/right edge cuts through still issues ONE 16-byte load: it starts up to 3 pixels before the
+// row or ends up to 3 pixels after it (previous/next row, or the guard band every image the kernels
+// read is allocated with) and the stray pixels are masked afterwards.  Lanes the layer does not
+// cover read offset 0 (a harmless broadcast) so that the loads of all four groups issue back to back
+// with no divergent branch -- conditional loads made hipcc drain vmcnt between groups, one HBM
+// round trip after another.
 struct Tap {
     int off;  // pixel offset from L.src (< 2^31: the host rejects layers of 2^31 pixels or more)
     int sx;   // layer column under pixel 0; -kLaneNPx when this lane does not read the layer
 };
 
-__device__ __forceinline__ Tap tap_regular(const Layer &L, const Group &G, bool has_layer) {
-    const int sy = G.y - L.dy, sx = G.x - L.dx;
+__device__ __forceinline__ Tap make_tap(const Layer &L, int x, int y, bool enable) {
+    const int sy = y - L.dy, sx = x - L.dx;
     // covered <=> 0 <= sy < h and -4 < sx < w (sign-bit trick, see run_hits)
-    const bool covered = has_layer && G.regular && ((sy | (L.h - 1 - sy) | (sx + kLaneNPx - 1) | (L.w - 1 - sx)) >= 0);
+    const bool covered = enable && ((sy | (L.h - 1 - sy) | (sx + kLaneNPx - 1) | (L.w - 1 - sx)) >= 0);
     Tap t;
     t.off = covered ? sy * L.w + sx : 0;
     t.sx = covered ? sx : -kLaneNPx;
     return t;
 }
 
-// Keep the loaded pixels that lie inside the layer row, zero (transparent) the rest.
-__device__ __forceinline__ u32x4 mask_tap(const Tap &t, const Layer &L, u32x4 v) {
+__device__ __forceinline__ u32x4 load_tap(const Layer &L, const Tap &t) {
+    // uniform base (SGPR pair) + unsigned 32-bit lane offset; the 16-byte bias keeps the offset
+    // non-negative when the load starts in the guard band before the cutout
+    const MIC_GLOBAL char *basep = reinterpret_cast<const MIC_GLOBAL char *>(L.src) - 16;
+    return __builtin_nontemporal_load(
+        reinterpret_cast<const MIC_GLOBAL u32x4_a4 *>(basep + (uint32_t)(t.off * 4 + 16)));
+}
+
+// Keep the loaded pixels j in [jlo, jhi) that lie inside the layer row, zero (transparent) the rest.
+__device__ __forceinline__ u32x4 mask_tap(const Tap &t, const Layer &L, u32x4 v, int jlo, int jhi) {
     u32x4 s;
 #pragma unroll
-    for (int j = 0; j < kLaneNPx; ++j) s[j] = (uint32_t)(t.sx + j) < (uint32_t)L.w ? v[j] : 0u;
+    for (int j = 0; j < kLaneNPx; ++j)
+        s[j] = ((uint32_t)(t.sx + j) < (uint32_t)L.w && j >= jlo && j < jhi) ? v[j] : 0u;
     return s;
 }
 
-// Row-straddling group (W % 4 != 0) or ragged canvas end: walk the pixels, no division (general
-// kernel only; such groups are one lane per canvas row).
-__device__ __forceinline__ u32x4 fetch_straddler(const Layer &L, const Group &G, int W) {
-    u32x4 s = (u32x4)(0u);
-    gcptr src = reinterpret_cast<gcptr>(L.src);
-    int x = G.x, y = G.y;
-#pragma unroll
-    for (int j = 0; j < kLaneNPx; ++j) {
-        if (j >= G.lo && j < G.hi) {
-            while (x >= W) {  // once when W >= 4
-                x -= W;
-                ++y;
-            }
-            const int sy = y - L.dy, sx = x - L.dx;
-            if (sy >= 0 && sy < L.h && sx >= 0 && sx < L.w) s[j] = load1(src + ((int64_t)sy * L.w + sx));
-            ++x;
+// First/last page of a canvas that does not start/end on a 4 KiB boundary, and canvases narrower
+// than 4 pixels: at most two pages per canvas, so this is written for obviousness, not speed --
+// one pixel at a time, every layer tested, Pillow's formula verbatim (it mirrors the oracle).
+__device__ __forceinline__ void edge_page(const Job &job, const Layer *jl, int64_t qp, int lane) {
+    const uint32_t W = (uint32_t)job.W;
+    const int64_t n_px = (int64_t)job.W * job.H;
+    gcptr bg = reinterpret_cast<gcptr>(job.bg);
+    gptr out = reinterpret_cast<gptr>(job.out);
+#pragma unroll 1
+    for (int i = 0; i < kGroups * kLaneNPx; ++i) {
+        const int64_t q = qp + (i / kLaneNPx) * kWavePx + lane * kLaneNPx + (i % kLaneNPx);
+        if (q < 0 || q >= n_px) continue;
+        const int y = (int)((uint32_t)q / W);
+        const int x = (int)((uint32_t)q - (uint32_t)y * W);
+        uint32_t p = job.bg != 0 ? load1(bg + q) : job.bg_rgba;
+#pragma unroll 1
+        for (int l = 0; l < job.layer_count; ++l) {
+            const Layer L = jl[l];
+            const int sx = x - L.dx, sy = y - L.dy;
+            if ((sx | sy | (L.w - 1 - sx) | (L.h - 1 - sy)) >= 0)
+                p = alpha_over(p, load1(reinterpret_cast<gcptr>(L.src) + ((int64_t)sy * L.w + sx)));
         }
+        store1(out + q, p);
     }
-    return s;
 }
 
-// (launch bounds: hipcc settles for 85 VGPRs = 5 waves/SIMD unless told that 7 are wanted; 70 VGPRs,
-// no spills.  8 waves would spill.)
-// HOT = jobs with W % 4 == 0, a 16-byte aligned canvas and a solid opaque background (what the
-// reference's pipeline produces: fill_solid canvases, background_resizing.py:32); every other job
-// (odd widths, background images, translucent colours) takes the general instantiation.
-template <bool HOT>
-__global__ __launch_bounds__(64, HOT ? 7 : 1) void composite_kernel(const Job *__restrict__ jobs,
-                                                       const Layer *__restrict__ layers) {
+// Instantiations (chosen per job on the host, mic_api.hip):
+//   ALIGNED  W % 4 == 0 and a 16-byte aligned canvas: no pixel group straddles a row end;
+//   SOLID    solid opaque background: nothing to read, destination alpha stays 255.
+// <true, true> is what the reference's pipeline produces (fill_solid canvases,
+// background_resizing.py:32).  Launch bounds: hipcc settles for 85 VGPRs (5 waves/SIMD) unless told
+// that more waves are wanted; 7 waves = 72 VGPRs fit without spills, 8 would spill.
+template <bool ALIGNED, bool SOLID>
+__global__ __launch_bounds__(64, (ALIGNED && SOLID) ? 7 : (SOLID ? 6 : 4)) void composite_kernel(
+    const Job *__restrict__ jobs, const Layer *__restrict__ layers) {
     const Job job = jobs[blockIdx.y];
     if ((int)blockIdx.x >= job.n_pages) return;
     const int lane = threadIdx.x;
     const int W = job.W;
     const int64_t n_px = (int64_t)job.W * job.H;
-    const bool wide = W >= kPagePx;  // a page then spans at most two rows
-    constexpr bool ALIGNED = HOT;
+    const Layer *jl = layers + job.layer_begin;
 
     const int64_t qp = (int64_t)blockIdx.x * kPagePx - job.px_shift;
     // pages that lie wholly inside the canvas: all but the first/last of a page-misaligned canvas
-    const bool interior = qp >= 0 && qp + kPagePx <= n_px;
+    if (qp < 0 || qp + kPagePx > n_px || W < kLaneNPx) {
+        edge_page(job, jl, qp, lane);
+        return;
+    }
     const int64_t q_lane = qp + lane * kLaneNPx;  // group r starts at q_lane + r * 256
-    // the four 256-pixel runs of the page, clipped to the canvas, as (row, column) of both ends,
-    // and this lane's four pixel groups
+
+    // The four 256-pixel runs of the page as (row, column) of both ends, and this lane's four
+    // pixel groups.  One wave-uniform division gives the row/column of the page's first pixel.
+    // (This is scalar-unit work, one unit per CU: kept lean.)
     int ra[kGroups], ca[kGroups], rb[kGroups], cb[kGroups];
-    bool live[kGroups];
     Group G[kGroups];
-    if (interior && wide) {
-        // The common case, kept lean (this is scalar-unit work, one unit per CU): the page lies
-        // inside a canvas at least one page wide, so it spans at most two rows.  One wave-uniform
-        // division gives the row/column of its first pixel; everything else is add/compare.
-        const uint32_t qa = (uint32_t)qp;
-        const int y0 = (int)(qa / (uint32_t)W);
-        const uint32_t x0 = qa - (uint32_t)y0 * (uint32_t)W;
+    const uint32_t uW = (uint32_t)W;
+    const int y0 = (int)((uint32_t)qp / uW);
+    const uint32_t x0 = (uint32_t)qp - (uint32_t)y0 * uW;
+    if (W >= kPagePx) {  // a page spans at most two rows: add/compare only
 #pragma unroll
         for (int r = 0; r < kGroups; ++r) {
             uint32_t xf = x0 + (uint32_t)(r * kWavePx);
             int yf = y0;
-            if (xf >= (uint32_t)W) { xf -= (uint32_t)W; yf += 1; }
+            if (xf >= uW) { xf -= uW; yf += 1; }
             uint32_t xl = xf + (uint32_t)(kWavePx - 1);
             int yl = yf;
-            if (xl >= (uint32_t)W) { xl -= (uint32_t)W; yl += 1; }
+            if (xl >= uW) { xl -= uW; yl += 1; }
             ra[r] = yf; ca[r] = (int)xf; rb[r] = yl; cb[r] = (int)xl;
-            live[r] = true;
             uint32_t x = xf + (uint32_t)(lane * kLaneNPx);
             int y = yf;
-            if (x >= (uint32_t)W) { x -= (uint32_t)W; y += 1; }
+            if (x >= uW) { x -= uW; y += 1; }
             G[r].x = (int)x;
             G[r].y = y;
-            G[r].lo = 0;
-            G[r].hi = kLaneNPx;
-            G[r].regular = ALIGNED || (int)x + kLaneNPx <= W;
+            G[r].k = ALIGNED ? kLaneNPx : min(kLaneNPx, W - (int)x);
         }
-    } else {
-        // first/last page of a page-misaligned canvas, or a canvas narrower than a page
-        // first page only: pixels of the page that precede the canvas (0 elsewhere)
-        const int lead = qp < 0 ? (int)(-qp) : 0;
-        // row/column of the page's first in-canvas pixel: the one wave-uniform division of the page
-        struct { int y0, x0; } pd;
-        {
-            const uint32_t qa = (uint32_t)max(qp, (int64_t)0);
-            pd.y0 = (int)(qa / (uint32_t)W);
-            pd.x0 = (int)(qa - (uint32_t)pd.y0 * (uint32_t)W);
-        }
-        // the four 256-pixel runs of the page, clipped to the canvas, as (row, column) of both ends
-    #pragma unroll
+    } else {  // narrow canvas: a run spans several rows
+#pragma unroll
         for (int r = 0; r < kGroups; ++r) {
-            const int first = max(r * kWavePx - lead, 0);  // offsets from the page's first in-canvas pixel
-            const int64_t last64 = min((int64_t)(r * kWavePx + kWavePx - 1 - lead), n_px - 1 - max(qp, (int64_t)0));
-            live[r] = last64 >= first && r * kWavePx + kWavePx > lead;
-            const int last = live[r] ? (int)last64 : first;
-            uint32_t xf = (uint32_t)pd.x0 + (uint32_t)first, xl = (uint32_t)pd.x0 + (uint32_t)last;
-            int yf = pd.y0, yl = pd.y0;
-            if (wide) {
-                if (xf >= (uint32_t)W) { xf -= (uint32_t)W; yf += 1; }
-                if (xl >= (uint32_t)W) { xl -= (uint32_t)W; yl += 1; }
-            } else {
-                const uint32_t df = xf / (uint32_t)W, dl = xl / (uint32_t)W;
-                yf += (int)df; xf -= df * (uint32_t)W;
-                yl += (int)dl; xl -= dl * (uint32_t)W;
-            }
-            ra[r] = yf; ca[r] = (int)xf; rb[r] = yl; cb[r] = (int)xl;
-        }
-
-    #pragma unroll
-        for (int r = 0; r < kGroups; ++r) {
-            const int in_page = r * kWavePx + lane * kLaneNPx;  // offset of pixel 0 inside the page
-            G[r].lo = 0;
-            G[r].hi = kLaneNPx;
-            if (!interior) {
-                const int64_t q = q_lane + r * kWavePx;
-                G[r].lo = (int)min(max(-q, (int64_t)0), (int64_t)kLaneNPx);
-                G[r].hi = (int)min(max(n_px - q, (int64_t)0), (int64_t)kLaneNPx);
-            }
-            // offset of the first in-canvas pixel from the page's first in-canvas pixel (pd.x0, pd.y0)
-            uint32_t x = (uint32_t)pd.x0 + (uint32_t)max(in_page - lead, 0);
-            int y = pd.y0;
-            if (wide) {
-                if (x >= (uint32_t)W) { x -= (uint32_t)W; y += 1; }
-            } else {
-                const uint32_t d = x / (uint32_t)W;
-                y += (int)d;
-                x -= d * (uint32_t)W;
-            }
-            G[r].x = (int)x;
-            G[r].y = y;
-            G[r].regular = G[r].lo == 0 && G[r].hi == kLaneNPx && (ALIGNED || (int)x + kLaneNPx <= W);
+            const uint32_t f = x0 + (uint32_t)(r * kWavePx), l = f + (uint32_t)(kWavePx - 1);
+            const uint32_t df = f / uW, dl = l / uW;
+            ra[r] = y0 + (int)df; ca[r] = (int)(f - df * uW);
+            rb[r] = y0 + (int)dl; cb[r] = (int)(l - dl * uW);
+            const uint32_t xq = f + (uint32_t)(lane * kLaneNPx), d = xq / uW;
+            G[r].x = (int)(xq - d * uW);
+            G[r].y = y0 + (int)d;
+            G[r].k = ALIGNED ? kLaneNPx : min(kLaneNPx, W - G[r].x);
         }
     }
 
     // ---- background ----
     u32x4 px[kGroups];
-    if (HOT || job.bg == 0) {
+    bool dst_opaque = true;  // every pixel this wave holds is opaque; then stays so (over 255 gives 255)
+    if (SOLID) {
 #pragma unroll
         for (int r = 0; r < kGroups; ++r) px[r] = (u32x4)(job.bg_rgba);
-    } else if (interior) {
-        gcptr bg = reinterpret_cast<gcptr>(job.bg) + q_lane;
+    } else if (job.bg == 0) {
 #pragma unroll
-        for (int r = 0; r < kGroups; ++r) px[r] = load4(bg + r * kWavePx);
+        for (int r = 0; r < kGroups; ++r) px[r] = (u32x4)(job.bg_rgba);
+        dst_opaque = (job.bg_rgba >> 24) == 255u;
     } else {
         gcptr bg = reinterpret_cast<gcptr>(job.bg) + q_lane;
+        uint32_t amin = 0xFFFFFFFFu;
 #pragma unroll
-        for (int r = 0; r < kGroups; ++r) {
-            px[r] = (u32x4)(0u);
-            if (ALIGNED) {
-                if (G[r].regular) px[r] = load4(bg + r * kWavePx);
-            } else {
+        for (int r = 0; r < kGroups; ++r) px[r] = load4(bg + r * kWavePx);
 #pragma unroll
-                for (int j = 0; j < kLaneNPx; ++j)
-                    if (j >= G[r].lo && j < G[r].hi) px[r][j] = load1(bg + (r * kWavePx + j));
-            }
-        }
-    }
-
-    // Is every pixel this wave holds opaque?  It then stays so: alpha-over onto alpha 255 gives 255.
-    bool dst_opaque = true;
-    if (!HOT) {
-        dst_opaque = (job.bg_rgba >> 24) == 255u;
-        if (job.bg != 0) {
-            uint32_t amin = 0xFFFFFFFFu;
+        for (int r = 0; r < kGroups; ++r)
 #pragma unroll
-            for (int r = 0; r < kGroups; ++r)
-#pragma unroll
-                for (int j = 0; j < kLaneNPx; ++j) amin = min(amin, px[r][j]);
-            dst_opaque = interior && !__any(amin < 0xFF000000u);
-        }
+            for (int j = 0; j < kLaneNPx; ++j) amin = min(amin, px[r][j]);
+        dst_opaque = !__any(amin < 0xFF000000u);
     }
 
     // ---- layers ----
@@ -313,7 +264,6 @@ __global__ __launch_bounds__(64, HOT ? 7 : 1) void composite_kernel(const Job *_
     // ITS OWN hit mask in list order: one round issues up to four independent 16-byte loads per lane
     // (one per group, possibly from four different layers) and then blends them.  A page touched by
     // three or four side-by-side objects needs one or two rounds, not one HBM round trip per object.
-    const Layer *jl = layers + job.layer_begin;
     for (int base = 0; base < job.layer_count; base += 64) {
         // cull 64 layers at once: lane l holds record base + l
         Layer mine{};
@@ -322,7 +272,7 @@ __global__ __launch_bounds__(64, HOT ? 7 : 1) void composite_kernel(const Job *_
             mine = jl[base + lane];
 #pragma unroll
             for (int r = 0; r < kGroups; ++r)
-                hit[r] = live[r] && run_hits(ra[r], ca[r], rb[r], cb[r], W, mine.dx, mine.dy, mine.w, mine.h);
+                hit[r] = run_hits(ra[r], ca[r], rb[r], cb[r], W, mine.dx, mine.dy, mine.w, mine.h);
         }
         uint64_t m[kGroups];
 #pragma unroll
@@ -350,55 +300,44 @@ __global__ __launch_bounds__(64, HOT ? 7 : 1) void composite_kernel(const Job *_
                 L[r].w = __builtin_amdgcn_readlane(mine.w, i);
                 L[r].h = __builtin_amdgcn_readlane(mine.h, i);
                 has_layer[r] = has;
-                tap[r] = tap_regular(L[r], G[r], has);
-                // uniform base (SGPR pair) + unsigned 32-bit lane offset -> the `saddr` form of
-                // global_load: no 64-bit address in vector registers.  The 16-byte bias keeps the
-                // offset non-negative when the load starts in the guard band before the cutout.
-                const MIC_GLOBAL char *basep = reinterpret_cast<const MIC_GLOBAL char *>(L[r].src) - 16;
-                s[r] = __builtin_nontemporal_load(
-                    reinterpret_cast<const MIC_GLOBAL u32x4_a4 *>(basep + (uint32_t)(tap[r].off * 4 + 16)));
+                tap[r] = make_tap(L[r], G[r].x, G[r].y, has);
+                s[r] = load_tap(L[r], tap[r]);
             }
 #pragma unroll
             for (int r = 0; r < kGroups; ++r) {  // consume
-                s[r] = mask_tap(tap[r], L[r], s[r]);
+                s[r] = mask_tap(tap[r], L[r], s[r], 0, ALIGNED ? kLaneNPx : G[r].k);
                 if (!ALIGNED) {
-                    if (__any(!G[r].regular) && L[r].w > 0) {
-                        const u32x4 t = fetch_straddler(L[r], G[r], W);
-                        if (!G[r].regular && has_layer[r]) s[r] = t;
+                    // a group that straddles a row end: its pixels k..3 continue at column 0 of the
+                    // next row -- one more masked 16-byte load, only in waves that hold such a group
+                    if (__any(G[r].k < kLaneNPx)) {
+                        const Tap t2 = make_tap(L[r], G[r].x - W, G[r].y + 1, has_layer[r] && G[r].k < kLaneNPx);
+                        const u32x4 v2 = mask_tap(t2, L[r], load_tap(L[r], t2), G[r].k, kLaneNPx);
+#pragma unroll
+                        for (int j = 0; j < kLaneNPx; ++j) s[r][j] |= v2[j];
                     }
                 }
             }
             // partial alpha anywhere in the wave?  (sa + 1) & 0xFE == 0  <=>  sa in {0, 255}
             uint32_t soft = 0;
 #pragma unroll
-            for (int r = 0; r < kGroups; ++r) {
-                {
+            for (int r = 0; r < kGroups; ++r)
 #pragma unroll
-                    for (int j = 0; j < kLaneNPx; ++j) soft |= ((s[r][j] >> 24) + 1u) & 0xFEu;
-                }
-            }
+                for (int j = 0; j < kLaneNPx; ++j) soft |= ((s[r][j] >> 24) + 1u) & 0xFEu;
             if (!__any(soft != 0)) {
                 // alpha 0 keeps dst, alpha 255 takes src: what the formula gives, exactly, for any dst
 #pragma unroll
-                for (int r = 0; r < kGroups; ++r) {
-                    {
+                for (int r = 0; r < kGroups; ++r)
 #pragma unroll
-                        for (int j = 0; j < kLaneNPx; ++j)
-                            px[r][j] = s[r][j] >= 0xFF000000u ? s[r][j] : px[r][j];
-                    }
-                }
-            } else if (HOT || dst_opaque) {
+                    for (int j = 0; j < kLaneNPx; ++j) px[r][j] = s[r][j] >= 0xFF000000u ? s[r][j] : px[r][j];
+            } else if (SOLID || dst_opaque) {
 #pragma unroll
-                for (int r = 0; r < kGroups; ++r) {
-                    {
+                for (int r = 0; r < kGroups; ++r)
 #pragma unroll
-                        for (int j = 0; j < kLaneNPx; ++j) px[r][j] = over_opaque_dst(px[r][j], s[r][j]);
-                    }
-                }
-            } else if (!HOT) {
-                // translucent destination (a background image with alpha < 255): the verbatim formula,
-                // one pixel at a time through ONE copy of the code (registers rotate), so that this
-                // rare path does not set the kernel's register budget
+                    for (int j = 0; j < kLaneNPx; ++j) px[r][j] = over_opaque_dst(px[r][j], s[r][j]);
+            } else if (!SOLID) {
+                // translucent destination (a background with alpha < 255): the verbatim formula, one
+                // pixel at a time through ONE copy of the code (registers rotate), so that this rare
+                // path does not set the kernel's register budget
 #pragma unroll 1
                 for (int it = 0; it < kGroups * kLaneNPx; ++it) {
                     const uint32_t o = alpha_over(px[0][0], s[0][0]);
@@ -417,35 +356,30 @@ __global__ __launch_bounds__(64, HOT ? 7 : 1) void composite_kernel(const Job *_
 
     // ---- the canvas is written exactly once: four coalesced 1 KiB stores per page ----
     gptr out = reinterpret_cast<gptr>(job.out) + q_lane;
-    if (interior) {
 #pragma unroll
-        for (int r = 0; r < kGroups; ++r) store4(out + r * kWavePx, px[r]);
-    } else {
-#pragma unroll
-        for (int r = 0; r < kGroups; ++r) {
-            if (ALIGNED) {
-                if (G[r].regular) store4(out + r * kWavePx, px[r]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < kLaneNPx; ++j)
-                    if (j >= G[r].lo && j < G[r].hi) store1(out + (r * kWavePx + j), px[r][j]);
-            }
-        }
-    }
+    for (int r = 0; r < kGroups; ++r) store4(out + r * kWavePx, px[r]);
 }
 
-hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_jobs, int n_hot, int pitch,
-                            hipStream_t stream) {
+// Jobs arrive sorted by class: [0, n0) aligned+solid, [n0, n1) unaligned+solid, [n1, n2) aligned with
+// a background image / translucent colour, [n2, n_jobs) neither.
+hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_jobs, const int class_end[3],
+                            int pitch, hipStream_t stream) {
     if (n_jobs <= 0 || pitch <= 0) return hipSuccess;
     // grid.x (= pitch) is a multiple of 8 so that (linear workgroup id) mod 8 == (page index) mod 8
     // for every job of the launch: the XCD <-> page residue pairing survives the 2-D grid.
-    // Jobs [0, n_hot) take the lean instantiation, the rest the general one (see composite_kernel).
-    if (n_hot > 0)
-        hipLaunchKernelGGL(composite_kernel<true>, dim3((unsigned)pitch, (unsigned)n_hot, 1), dim3(64), 0,
-                           stream, jobs_dev, layers_dev);
-    if (n_jobs > n_hot)
-        hipLaunchKernelGGL(composite_kernel<false>, dim3((unsigned)pitch, (unsigned)(n_jobs - n_hot), 1),
-                           dim3(64), 0, stream, jobs_dev + n_hot, layers_dev);
+    const int b[5] = {0, class_end[0], class_end[1], class_end[2], n_jobs};
+    if (b[1] > b[0])
+        hipLaunchKernelGGL((composite_kernel<true, true>), dim3((unsigned)pitch, (unsigned)(b[1] - b[0])), dim3(64),
+                           0, stream, jobs_dev + b[0], layers_dev);
+    if (b[2] > b[1])
+        hipLaunchKernelGGL((composite_kernel<false, true>), dim3((unsigned)pitch, (unsigned)(b[2] - b[1])), dim3(64),
+                           0, stream, jobs_dev + b[1], layers_dev);
+    if (b[3] > b[2])
+        hipLaunchKernelGGL((composite_kernel<true, false>), dim3((unsigned)pitch, (unsigned)(b[3] - b[2])), dim3(64),
+                           0, stream, jobs_dev + b[2], layers_dev);
+    if (b[4] > b[3])
+        hipLaunchKernelGGL((composite_kernel<false, false>), dim3((unsigned)pitch, (unsigned)(b[4] - b[3])), dim3(64),
+                           0, stream, jobs_dev + b[3], layers_dev);
     return hipGetLastError();
 }
 

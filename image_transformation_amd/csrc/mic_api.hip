@@ -654,12 +654,19 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         max_pages = std::max(max_pages, d.n_pages);
     }
     const int pitch = (max_pages + 7) / 8 * 8;
-    // hot jobs first (lean kernel instantiation): W % 4 == 0, 16-byte aligned canvas, opaque solid bg
-    auto is_hot = [](const Job &d) {
-        return d.W % 4 == 0 && d.out % 16 == 0 && d.bg == 0 && (d.bg_rgba >> 24) == 255u;
+    // sort the job table by kernel class (see launch_composite): 0 = aligned + solid opaque
+    // background (the pipeline's own canvases), 1 = unaligned + solid, 2 = aligned + other, 3 = rest
+    auto job_class = [](const Job &d) {
+        const bool aligned = d.W % 4 == 0 && d.out % 16 == 0;
+        const bool solid = d.bg == 0 && (d.bg_rgba >> 24) == 255u;
+        return (solid ? 0 : 2) + (aligned ? 0 : 1);
     };
     P->ordered = P->jobs;
-    const int n_hot = (int)(std::stable_partition(P->ordered.begin(), P->ordered.end(), is_hot) - P->ordered.begin());
+    std::stable_sort(P->ordered.begin(), P->ordered.end(),
+                     [&](const Job &a, const Job &b) { return job_class(a) < job_class(b); });
+    int class_end[3] = {0, 0, 0};
+    for (const Job &d : P->ordered)
+        for (int c = job_class(d); c < 3; ++c) ++class_end[c];
 
     // the job table always travels (output pointers change per run); the rest only for transient plans
     const size_t upload = P->persistent ? sizeof(Job) * P->ordered.size() : P->total;
@@ -689,7 +696,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
                               P->pt.max_v_out_w, P->pt.max_v_out_h, stream));
     if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
     HIP_TRY(launch_composite(reinterpret_cast<const Job *>(dp), reinterpret_cast<const Layer *>(dp + P->off_layers),
-                             n_jobs, n_hot, pitch, stream));
+                             n_jobs, class_end, pitch, stream));
     if (prof) {
         HIP_TRY(hipEventRecord(pe[2], stream));
         ++ctx->prof_calls;

@@ -72,9 +72,10 @@ struct alignas(16) RsJob {
 static_assert(sizeof(RsJob) == 64, "RsJob layout");
 
 // ---- launchers (defined next to their kernels) -----------------------------------------------
-// Jobs [0, n_hot) are "hot" (W % 4 == 0, canvas 16-byte aligned, solid opaque background), the
-// rest take the general kernel instantiation.  pitch = max pages per job rounded up to 8.
-hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_jobs, int n_hot,
+// The job table is sorted by kernel class; class_end[c] = one past the last job of class c for
+// c = 0 (aligned + solid opaque background), 1 (unaligned + solid), 2 (aligned + other background);
+// the rest is class 3.  pitch = max pages per job rounded up to 8.
+hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_jobs, const int class_end[3],
                             int pitch, hipStream_t stream);
 hipError_t launch_resample_h(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_rows,
                              hipStream_t stream);
