@@ -7,10 +7,12 @@
 // of the image (4 B/px): HBM-bound.
 //
 // Histogram kernel: per-wavefront private LDS histograms.  Backgrounds are mostly flat, so within
-// a wave many lanes hit the same bin; instead of letting same-address LDS atomics serialise, the
-// wave first aggregates equal values with readlane/__ballot/popcount for a couple of rounds (one
-// atomic per distinct value), and only the leftovers (noisy regions, mostly distinct bins) go
-// through plain LDS atomics.  Per-block totals are flushed with one global atomic per non-empty bin.
+// a wave all lanes often hit the same bin; instead of letting 64 same-address LDS atomics serialise,
+// the wave checks for that case with readlane/__ballot and lets one lane add the population count.
+// Otherwise (noisy regions, mostly distinct bins) every lane issues its own LDS atomic.  Per-block
+// totals are flushed with one global atomic per non-empty bin.
+#include <algorithm>
+
 #include "mic_internal.h"
 
 namespace mic {
@@ -18,26 +20,24 @@ namespace mic {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kHistWaves = 4;
-constexpr int kAggRounds = 2;
 
 // hist layout (uint32): [set][channel][256], set 0 = alpha > 0, set 1 = all pixels;
 // then counts[2] at kCountOff.
 constexpr int kCountOff = 2 * 3 * 256;
 
 __device__ __forceinline__ void wave_hist_add(uint32_t *h, uint32_t v, bool valid, int lane) {
-    unsigned long long todo = __ballot(valid);
-#pragma unroll
-    for (int round = 0; round < kAggRounds; ++round) {
-        if (todo == 0) return;
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t lv = __shfl(v, leader);
-        const bool same = valid && v == lv;
-        const unsigned long long m = __ballot(same);
-        if (lane == leader) atomicAdd(&h[lv], (uint32_t)__popcll(m));
-        if (same) valid = false;
-        todo &= ~m;
+    // Backgrounds are mostly flat: if every participating lane of the wave holds the same value, one
+    // lane adds the population count (readfirstlane + compare + ballot); otherwise every lane issues
+    // its own LDS atomic (noise spreads over the bins, so those rarely collide).
+    const unsigned long long todo = __ballot(valid);
+    if (todo == 0) return;
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t lv = (uint32_t)__builtin_amdgcn_readlane((int)v, leader);
+    if (__ballot(valid && v != lv) == 0) {
+        if (lane == leader) atomicAdd(&h[lv], (uint32_t)__popcll(todo));
+    } else if (valid) {
+        atomicAdd(&h[v], 1u);
     }
-    if (valid) atomicAdd(&h[v], 1u);
 }
 
 // mode 0: pixels with alpha > 0.  mode 1: all pixels, skipped entirely unless counts[0] == 0.
@@ -150,8 +150,9 @@ hipError_t launch_median(const void *rgba, size_t n_px, uint32_t *hist_dev, uint
         const uint32_t *p = reinterpret_cast<const uint32_t *>(rgba);
         hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)blocks), dim3(64 * kHistWaves), 0, stream,
                            p, n_px, hist_dev, 0);
-        hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)blocks), dim3(64 * kHistWaves), 0, stream,
-                           p, n_px, hist_dev, 1);
+        // all-pixels fallback: exits at once unless the image had no pixel with alpha > 0
+        hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)std::min<size_t>(blocks, 512)), dim3(64 * kHistWaves),
+                           0, stream, p, n_px, hist_dev, 1);
     }
     hipLaunchKernelGGL(median_select_kernel, dim3(1), dim3(256), 0, stream, hist_dev, out_rgba_dev);
     return hipGetLastError();

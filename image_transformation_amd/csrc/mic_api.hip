@@ -110,6 +110,7 @@ struct CoefEntry {
     int ksize = 0;
     int32_t *bounds = nullptr;  // device
     int32_t *coeffs = nullptr;  // device
+    std::vector<int32_t> bounds_host;  // [out][2], for sizing the fused kernel's LDS windows
 };
 }  // namespace
 
@@ -265,6 +266,7 @@ static int get_coefs(mic_ctx *ctx, int in, int out, int filter, bool transposed,
     AxisTable t = build_axis_table(in, out, filter);
     CoefEntry e;
     e.ksize = t.ksize;
+    e.bounds_host = t.bounds;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e.bounds), t.bounds.size() * sizeof(int32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e.coeffs), t.coeffs.size() * sizeof(int32_t)));
     // Pageable source: the runtime stages it before returning, the vectors may die afterwards.
@@ -421,21 +423,77 @@ namespace {
 struct ResizePlan {
     uint64_t src;
     int sw, sh, dw, dh;
-    size_t tmp_off = 0;   // arena offset of the horizontal pass output (if both axes change)
-    size_t dst_off = 0;   // arena offset of the final image (unused when dst_ptr is set)
+    size_t tmp_off = 0;   // scratch offset of the horizontal pass output (two-pass fallback, both axes)
+    size_t dst_off = 0;   // scratch offset of the final image (unused when dst_ptr is set)
     uint64_t dst_ptr = 0; // caller-provided destination (mic_resize)
+    // fused kernel (source window + 8-bit intermediate in LDS); tx == 0: two-pass fallback
+    int tx = 0, ty = 0, max_c = 0, max_r = 0;
 };
 
 struct PassTables {
+    std::vector<RsFused> fused;
+    int fused_max_tiles = 0;
+    size_t fused_lds = 0;
     std::vector<RsJob> h, v;
     int max_h_out_w = 0, max_h_rows = 0, max_v_out_w = 0, max_v_out_h = 0;
 };
+
+// Largest source extent (first tap of the tile's first sample .. last tap of its last sample) over
+// all tiles of `tile` output samples along one axis.
+int max_window(const std::vector<int32_t> &bounds, int out, int tile) {
+    int best = 0;
+    for (int o0 = 0; o0 < out; o0 += tile) {
+        const int o1 = std::min(out, o0 + tile) - 1;
+        best = std::max(best, bounds[2 * o1] + bounds[2 * o1 + 1] - bounds[2 * o0]);
+    }
+    return best;
+}
+
+// Pick the output tile of the fused kernel for one layer: the biggest of a short list whose source
+// window + intermediate + coefficient slices fit LDS.  Leaves tx == 0 when nothing fits.
+int choose_fused(mic_ctx *ctx, ResizePlan *p, int filter) {
+    const bool need_h = p->dw != p->sw, need_v = p->dh != p->sh;
+    CoefEntry ch, cv;
+    if (need_h) if (int rc = get_coefs(ctx, p->sw, p->dw, filter, false, &ch)) return rc;
+    if (need_v) if (int rc = get_coefs(ctx, p->sh, p->dh, filter, false, &cv)) return rc;
+    const int kx = need_h ? ch.ksize : 0, ky = need_v ? cv.ksize : 0;
+    static const int kTiles[][2] = {{64, 16}, {64, 8}, {64, 4}, {32, 4}, {32, 2}, {16, 2}, {16, 1}};
+    for (const auto &t : kTiles) {
+        const int tx = t[0], ty = t[1];
+        const int mc = need_h ? max_window(ch.bounds_host, p->dw, tx) : tx;
+        const int mr = need_v ? max_window(cv.bounds_host, p->dh, ty) : ty;
+        if (rs_fused_lds_bytes(mc, mr, tx, ty, kx, ky) <= kRsFusedMaxLds) {
+            p->tx = tx; p->ty = ty; p->max_c = mc; p->max_r = mr;
+            return MIC_OK;
+        }
+    }
+    p->tx = 0;
+    return MIC_OK;
+}
 
 int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, void *scratch, PassTables *pt) {
     const uint64_t arena = reinterpret_cast<uint64_t>(scratch);
     for (const ResizePlan &p : plans) {
         const bool need_h = p.dw != p.sw, need_v = p.dh != p.sh;
         const uint64_t dst = p.dst_ptr ? p.dst_ptr : arena + p.dst_off;
+        if (p.tx > 0) {
+            CoefEntry ch, cv;
+            if (need_h) if (int rc = get_coefs(ctx, p.sw, p.dw, filter, false, &ch)) return rc;
+            if (need_v) if (int rc = get_coefs(ctx, p.sh, p.dh, filter, false, &cv)) return rc;
+            RsFused f{};
+            f.src = p.src; f.dst = dst;
+            f.hbounds = reinterpret_cast<uint64_t>(ch.bounds); f.hcoeffs = reinterpret_cast<uint64_t>(ch.coeffs);
+            f.vbounds = reinterpret_cast<uint64_t>(cv.bounds); f.vcoeffs = reinterpret_cast<uint64_t>(cv.coeffs);
+            f.sw = p.sw; f.sh = p.sh; f.dw = p.dw; f.dh = p.dh;
+            f.kx = need_h ? ch.ksize : 0; f.ky = need_v ? cv.ksize : 0;
+            f.tx = p.tx; f.ty = p.ty;
+            f.tiles_x = (p.dw + p.tx - 1) / p.tx; f.tiles_y = (p.dh + p.ty - 1) / p.ty;
+            f.max_c = p.max_c; f.max_r = p.max_r;
+            pt->fused.push_back(f);
+            pt->fused_max_tiles = std::max(pt->fused_max_tiles, f.tiles_x * f.tiles_y);
+            pt->fused_lds = std::max(pt->fused_lds, rs_fused_lds_bytes(f.max_c, f.max_r, f.tx, f.ty, f.kx, f.ky));
+            continue;
+        }
         uint64_t v_src = p.src;
         uint32_t v_flags = kRsUnpremultiplyOnStore | kRsPremultiplyOnLoad;
         if (need_h) {
@@ -493,13 +551,14 @@ struct mic_plan {
     void *scratch = nullptr;   // resampled layers (persistent plans own it; transient ones borrow ctx->arena)
     size_t scratch_bytes = 0;
     void *tables_dev = nullptr;  // persistent plans: jobs | layers | h passes | v passes
-    size_t off_layers = 0, off_h = 0, off_v = 0, total = 0;
+    size_t off_layers = 0, off_f = 0, off_h = 0, off_v = 0, total = 0;
     mic_stats stats{};
 };
 
 static void plan_offsets(mic_plan *P) {
     P->off_layers = align_up(sizeof(Job) * P->jobs.size(), 64);
-    P->off_h = align_up(P->off_layers + sizeof(Layer) * P->layers.size(), 64);
+    P->off_f = align_up(P->off_layers + sizeof(Layer) * P->layers.size(), 64);
+    P->off_h = align_up(P->off_f + sizeof(RsFused) * P->pt.fused.size(), 64);
     P->off_v = align_up(P->off_h + sizeof(RsJob) * P->pt.h.size(), 64);
     P->total = align_up(P->off_v + sizeof(RsJob) * P->pt.v.size(), 64);
 }
@@ -582,7 +641,8 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                     ResizePlan rp{};
                     rp.src = reinterpret_cast<uint64_t>(A->blob) + E.offset;
                     rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
-                    if (rp.dw != rp.sw && rp.dh != rp.sh) {
+                    if (int rc = choose_fused(ctx, &rp, filter)) return rc;
+                    if (rp.tx == 0 && rp.dw != rp.sw && rp.dh != rp.sh) {
                         rp.tmp_off = scratch_need;
                         scratch_need = align_up(scratch_need + (size_t)rp.dw * rp.sh * 4 + kGuard, kPixelAlign);
                     }
@@ -623,6 +683,9 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
         if (!P->layers.empty())
             HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_layers, P->layers.data(),
                               sizeof(Layer) * P->layers.size(), hipMemcpyHostToDevice));
+        if (!P->pt.fused.empty())
+            HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_f, P->pt.fused.data(),
+                              sizeof(RsFused) * P->pt.fused.size(), hipMemcpyHostToDevice));
         if (!P->pt.h.empty())
             HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_h, P->pt.h.data(),
                               sizeof(RsJob) * P->pt.h.size(), hipMemcpyHostToDevice));
@@ -680,6 +743,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     } else {
         dp = static_cast<char *>(slot->dev);
         if (!P->layers.empty()) memcpy(hp + P->off_layers, P->layers.data(), sizeof(Layer) * P->layers.size());
+        if (!P->pt.fused.empty()) memcpy(hp + P->off_f, P->pt.fused.data(), sizeof(RsFused) * P->pt.fused.size());
         if (!P->pt.h.empty()) memcpy(hp + P->off_h, P->pt.h.data(), sizeof(RsJob) * P->pt.h.size());
         if (!P->pt.v.empty()) memcpy(hp + P->off_v, P->pt.v.data(), sizeof(RsJob) * P->pt.v.size());
     }
@@ -690,6 +754,8 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     const bool prof = ctx->profiling && ctx->prof_calls < ctx->prof_max;
     hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], stream));
+    HIP_TRY(launch_resample_fused(reinterpret_cast<const RsFused *>(dp + P->off_f), (int)P->pt.fused.size(),
+                                  P->pt.fused_max_tiles, P->pt.fused_lds, stream));
     HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + P->off_h), (int)P->pt.h.size(),
                               P->pt.max_h_out_w, P->pt.max_h_rows, stream));
     HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + P->off_v), (int)P->pt.v.size(),
@@ -814,22 +880,26 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
     rp.src = reinterpret_cast<uint64_t>(src_dev);
     rp.sw = src_w; rp.sh = src_h; rp.dw = dst_w; rp.dh = dst_h;
     rp.dst_ptr = reinterpret_cast<uint64_t>(dst_dev);
+    if (int rc = choose_fused(ctx, &rp, filter)) return rc;
     size_t need = 0;
-    if (dst_w != src_w && dst_h != src_h) need = (size_t)dst_w * src_h * 4;
+    if (rp.tx == 0 && dst_w != src_w && dst_h != src_h) need = (size_t)dst_w * src_h * 4 + kGuard;
     if (int rc = ensure_arena(ctx, need)) return rc;
     PassTables pt;
     std::vector<ResizePlan> plans{rp};
     if (int rc = plan_passes(ctx, plans, filter, ctx->arena, &pt)) return rc;
-    const size_t off_v = 64;
+    const size_t off_v = 64, off_f = 128, total = 128 + sizeof(RsFused);
     Slot *slot = nullptr;
-    if (int rc = acquire_slot(ctx, 128, &slot)) return rc;
+    if (int rc = acquire_slot(ctx, total, &slot)) return rc;
     char *hp = static_cast<char *>(slot->host);
     if (!pt.h.empty()) memcpy(hp, pt.h.data(), sizeof(RsJob));
     if (!pt.v.empty()) memcpy(hp + off_v, pt.v.data(), sizeof(RsJob));
-    HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, 128, hipMemcpyHostToDevice, stream));
+    if (!pt.fused.empty()) memcpy(hp + off_f, pt.fused.data(), sizeof(RsFused));
+    HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, total, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(slot->ev, stream));
     slot->pending = true;
     char *dp = static_cast<char *>(slot->dev);
+    HIP_TRY(launch_resample_fused(reinterpret_cast<const RsFused *>(dp + off_f), (int)pt.fused.size(),
+                                  pt.fused_max_tiles, pt.fused_lds, stream));
     HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp), (int)pt.h.size(), pt.max_h_out_w,
                               pt.max_h_rows, stream));
     HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + off_v), (int)pt.v.size(), pt.max_v_out_w,

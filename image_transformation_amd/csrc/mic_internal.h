@@ -71,6 +71,26 @@ struct alignas(16) RsJob {
 };
 static_assert(sizeof(RsJob) == 64, "RsJob layout");
 
+// One layer resized by the fused kernel: both axes in one launch, source tile and 8-bit
+// intermediate in LDS.  k? == 0 means that axis keeps its size (Pillow skips that pass).
+struct alignas(16) RsFused {
+    uint64_t src, dst;
+    uint64_t hbounds, hcoeffs;  // [dw][2], [dw][kx] (NOT transposed; the tile's slice is staged in LDS)
+    uint64_t vbounds, vcoeffs;  // [dh][2], [dh][ky]
+    int32_t sw, sh, dw, dh;
+    int32_t kx, ky;
+    int32_t tx, ty;             // output tile
+    int32_t tiles_x, tiles_y;
+    int32_t max_c, max_r;       // source window capacity of a tile (columns, rows)
+    int32_t pad[4];
+};
+static_assert(sizeof(RsFused) == 112, "RsFused layout");
+inline size_t rs_fused_lds_bytes(int max_c, int max_r, int tx, int ty, int kx, int ky) {
+    return 4 * ((size_t)max_r * max_c + (size_t)max_r * tx + (size_t)kx * tx + (size_t)ty * ky + 2 * (size_t)tx +
+                2 * (size_t)ty);
+}
+constexpr size_t kRsFusedMaxLds = 60 * 1024;
+
 // ---- launchers (defined next to their kernels) -----------------------------------------------
 // The job table is sorted by kernel class; class_end[c] = one past the last job of class c for
 // c = 0 (aligned + solid opaque background), 1 (unaligned + solid), 2 (aligned + other background);
@@ -81,6 +101,8 @@ hipError_t launch_resample_h(const RsJob *jobs_dev, int n_jobs, int max_out_w, i
                              hipStream_t stream);
 hipError_t launch_resample_v(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_out_h,
                              hipStream_t stream);
+hipError_t launch_resample_fused(const RsFused *jobs_dev, int n_jobs, int max_tiles, size_t lds_bytes,
+                                 hipStream_t stream);
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);
 // hist: uint32 [2][3][256] + counts[2]; zeroed by the launcher.
 hipError_t launch_median(const void *rgba, size_t n_px, uint32_t *hist_dev, uint32_t *out_rgba_dev,

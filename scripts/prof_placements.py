@@ -1,0 +1,14 @@
+"""A few runs of the C3 placements-mode (LANCZOS) composite for rocprofv3."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from image_transformation_amd import synthetic
+from image_transformation_amd.compositor import Atlas, CompositeBatch, SolidCanvas, coerce_placements
+size, objs, pl = synthetic.placements_workload(3840, 2160, 32, 3, "soft")
+atlas = Atlas(objs)
+plan = CompositeBatch(atlas, [SolidCanvas(size, synthetic.SOLID_BG)], [coerce_placements(atlas, pl)])
+out = plan.alloc_outputs()
+for _ in range(int(os.environ.get("MIC_ITERS", "6"))):
+    plan.run(out)
+torch.cuda.synchronize()
+print(plan.stats())

@@ -62,3 +62,13 @@ def test_packed_lanes_match_scalar():
         want |= c.astype(np.uint64) << sh
     want |= 0xFF000000
     assert np.array_equal(packed, want)
+
+
+def test_unpremultiply_reciprocal_table_exhaustive():
+    """kernels_resample.hip: 255*c // a == mulhi(c << 8, ceil(255 * 2^24 / a)) for 0 < a < 255."""
+    c = np.arange(256, dtype=np.uint64)
+    for a in range(1, 255):
+        R = -(-(255 << 24) // a)
+        assert R < 2 ** 32
+        q = ((c << np.uint64(8)) * np.uint64(R)) >> np.uint64(32)
+        assert np.array_equal(q, (255 * c) // a), a
