@@ -78,10 +78,17 @@ def main():
             raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # MIC_BENCH_REHEARSAL=1: all ranks share cuda:0 over gloo (to exercise the N>1 code path on a
+    # one-GPU box); never set by the driver, whose ranks get one GPU each over RCCL.
+    rehearsal = os.environ.get("MIC_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from image_transformation_amd import _native, flex, synthetic
     from image_transformation_amd.batch import broadcast_atlas, shard_indices

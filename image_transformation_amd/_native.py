@@ -90,6 +90,13 @@ SYMBOLS = {
 
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     """dlopen libmic.so and declare every prototype.  Needs no GPU (symbols only)."""
+    if not os.path.exists(path) and path == LIB_PATH:
+        # not a fallback: the HIP library itself is (re)built when hipcc is at hand (a fresh checkout)
+        try:
+            from . import build as _build
+            _build.build()
+        except Exception:
+            pass
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `python -m image_transformation_amd.build` "

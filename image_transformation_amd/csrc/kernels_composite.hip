@@ -70,13 +70,17 @@ __device__ __forceinline__ uint32_t over_opaque_dst(uint32_t d, uint32_t s) {
     return rb | (g << 8) | 0xFF000000u;
 }
 
-// Streaming accesses: every byte is touched once, so nontemporal hints on both sides.
+// Canvas traffic is touched once: nontemporal hints (background reads, canvas stores).
 __device__ __forceinline__ u32x4 load4(gcptr p) {
     return __builtin_nontemporal_load(reinterpret_cast<const MIC_GLOBAL u32x4_a4 *>(p));
 }
 __device__ __forceinline__ uint32_t load1(gcptr p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void store4(gptr p, u32x4 v) {
+#ifdef MIC_PLAIN_STORES
+    *reinterpret_cast<MIC_GLOBAL u32x4_a4 *>(p) = v;
+#else
     __builtin_nontemporal_store(v, reinterpret_cast<MIC_GLOBAL u32x4_a4 *>(p));
+#endif
 }
 __device__ __forceinline__ void store1(gptr p, uint32_t v) { __builtin_nontemporal_store(v, p); }
 
@@ -135,8 +139,15 @@ __device__ __forceinline__ u32x4 load_tap(const Layer &L, const Tap &t) {
     // uniform base (SGPR pair) + unsigned 32-bit lane offset; the 16-byte bias keeps the offset
     // non-negative when the load starts in the guard band before the cutout
     const MIC_GLOBAL char *basep = reinterpret_cast<const MIC_GLOBAL char *>(L.src) - 16;
+    // Default cache policy on purpose: the atlas is shared by every canvas of a batch and by
+    // neighbouring pages, and lives in L2 / the Infinity Cache between uses.  Nontemporal loads here
+    // cost 15% of the kernel (C3 batch: 134.7 -> 114.8 us); nontemporal STORES are worth +5%.
+#ifdef MIC_SRC_NT_LOADS
     return __builtin_nontemporal_load(
         reinterpret_cast<const MIC_GLOBAL u32x4_a4 *>(basep + (uint32_t)(t.off * 4 + 16)));
+#else
+    return *reinterpret_cast<const MIC_GLOBAL u32x4_a4 *>(basep + (uint32_t)(t.off * 4 + 16));
+#endif
 }
 
 // Keep the loaded pixels j in [jlo, jhi) that lie inside the layer row, zero (transparent) the rest.
