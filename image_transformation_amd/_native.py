@@ -80,6 +80,8 @@ SYMBOLS = {
     "mic_median_rgb": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8), _P]),
     "mic_median_rgb_dev": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P]),
     "mic_fill_solid": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8), _P]),
+    "mic_fill_gradient": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8),
+                                         ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, _P]),
     "mic_thumbnail_size": (ctypes.c_int, [ctypes.c_int32] * 4 + [_I32P, _I32P]),
     "mic_last_stats": (ctypes.c_int, [_P, ctypes.POINTER(Stats)]),
     "mic_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),

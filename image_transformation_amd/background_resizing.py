@@ -67,3 +67,47 @@ def fill_solid(background_path: str, canvas_size: Tuple[int, int]) -> Image.Imag
     (background_resizing.py:25-33)."""
     sc = solid_canvas(background_path, canvas_size)
     return _to_pil(fill_solid_device(sc.size, sc.rgba))
+
+
+# ------------------------------------------------------------------------------------------ gradient
+# background_resizing.py:36-98 of the reference (uncalled there today; README roadmap item, SURVEY.md
+# section 8f row 3): medians of four 8-pixel edge strips, then a linear gradient along the axis whose
+# two medians are closer.
+
+def _edge_strip_median_colors(img: Image.Image, strip_px: int = 8):
+    """(left, right, top, bottom) median colours of the image's edge strips
+    (background_resizing.py:36-57); each via the histogram-median kernel."""
+    ctx = _native.context()
+    arr = _image_to_array(img.convert("RGBA"))
+    dev = _upload(arr, ctx)
+    h, w = arr.shape[0], arr.shape[1]
+    strips = (dev[:, :min(strip_px, w)], dev[:, max(0, w - strip_px):],
+              dev[:min(strip_px, h)], dev[max(0, h - strip_px):])
+    return tuple(median_color_device(s.contiguous(), ctx) for s in strips)
+
+
+def _axis_variance(c1, c2) -> float:
+    return float((c1[0] - c2[0]) ** 2 + (c1[1] - c2[1]) ** 2 + (c1[2] - c2[2]) ** 2)
+
+
+def fill_gradient_device(canvas_size: Tuple[int, int], c1, c2, vertical: bool, device: Optional[int] = None):
+    """The gradient canvas as a device tensor (H, W, 4)."""
+    import torch
+
+    ctx = _native.context(device)
+    W, H = int(canvas_size[0]), int(canvas_size[1])
+    out = torch.empty((H, W, 4), dtype=torch.uint8, device=ctx.torch_device)
+    a = (ctypes.c_uint8 * 3)(*[int(v) for v in c1])
+    b = (ctypes.c_uint8 * 3)(*[int(v) for v in c2])
+    _native.check(_native.lib().mic_fill_gradient(ctx.handle, _P(out.data_ptr()), W, H, a, b, 1 if vertical else 0,
+                                                  _P(ctx.stream_ptr())))
+    return out
+
+
+def fill_gradient(background_path: str, canvas_size: Tuple[int, int]) -> Image.Image:
+    """Linear gradient background from edge medians (background_resizing.py:60-98): horizontal
+    (left -> right) if the left/right medians are at most as far apart as top/bottom, else vertical."""
+    left, right, top, bottom = _edge_strip_median_colors(_load_background_rgba(background_path))
+    if _axis_variance(left, right) <= _axis_variance(top, bottom):
+        return _to_pil(fill_gradient_device(canvas_size, left, right, vertical=False))
+    return _to_pil(fill_gradient_device(canvas_size, top, bottom, vertical=True))

@@ -44,8 +44,10 @@ def _image_to_array(img: Image.Image) -> np.ndarray:
 
 def _upload(arr: np.ndarray, ctx: _native.Context):
     torch = _torch()
-    t = torch.from_numpy(np.ascontiguousarray(arr))
-    return t.to(ctx.torch_device, non_blocking=False)
+    arr = np.ascontiguousarray(arr)
+    if not arr.flags.writeable:  # PIL-backed views are read-only; torch wants a writable buffer
+        arr = arr.copy()
+    return torch.from_numpy(arr).to(ctx.torch_device, non_blocking=False)
 
 
 def _to_pil(canvas_dev) -> Image.Image:

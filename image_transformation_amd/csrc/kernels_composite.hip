@@ -191,8 +191,11 @@ __device__ __forceinline__ void edge_page(const Job &job, const Layer *jl, int64
 // <true, true> is what the reference's pipeline produces (fill_solid canvases,
 // background_resizing.py:32).  Launch bounds: hipcc settles for 85 VGPRs (5 waves/SIMD) unless told
 // that more waves are wanted; 7 waves = 72 VGPRs fit without spills, 8 would spill.
+#ifndef MIC_HOT_WAVES
+#define MIC_HOT_WAVES 7
+#endif
 template <bool ALIGNED, bool SOLID>
-__global__ __launch_bounds__(64, (ALIGNED && SOLID) ? 7 : (SOLID ? 6 : 4)) void composite_kernel(
+__global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6 : 4)) void composite_kernel(
     const Job *__restrict__ jobs, const Layer *__restrict__ layers) {
     const Job job = jobs[blockIdx.y];
     if ((int)blockIdx.x >= job.n_pages) return;
@@ -406,6 +409,44 @@ __global__ __launch_bounds__(256) void fill_kernel(uint32_t *__restrict__ out, u
         for (int j = 0; j < kLaneNPx; ++j)
             if (q0 + j >= 0 && q0 + j < n_px) store1(o + (q0 + j), rgba);
     }
+}
+
+// fill_gradient's pixel loop (background_resizing.py:80-94): along one axis, position i of n gets
+// rgb = (1 - t) * c1 + t * c2 with t = i / max(1, n - 1), evaluated the way NumPy evaluates it there
+// -- t in double, (1 - t) and t rounded to float32, two float32 products and one float32 sum, each
+// rounded (no FMA contraction) -- then truncated by astype(uint8); alpha 255.
+__global__ __launch_bounds__(256) void gradient_kernel(uint32_t *__restrict__ out, int W, int H, float c1r,
+                                                       float c1g, float c1b, float c2r, float c2g, float c2b,
+                                                       int vertical) {
+    const int64_t n_px = (int64_t)W * H;
+    const int64_t q0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * kLaneNPx;
+    if (q0 >= n_px) return;
+    const int n = vertical ? H : W;
+    const double denom = (double)max(1, n - 1);
+    gptr o = (gptr)out;
+    int y = (int)(q0 / W), x = (int)(q0 - (int64_t)y * W);
+#pragma unroll
+    for (int j = 0; j < kLaneNPx; ++j) {
+        if (q0 + j >= n_px) break;
+        const double t = (double)(vertical ? y : x) / denom;
+        const float a = (float)(1.0 - t), b = (float)t;
+        const uint32_t r = (uint32_t)__fadd_rn(__fmul_rn(a, c1r), __fmul_rn(b, c2r));
+        const uint32_t g = (uint32_t)__fadd_rn(__fmul_rn(a, c1g), __fmul_rn(b, c2g));
+        const uint32_t bl = (uint32_t)__fadd_rn(__fmul_rn(a, c1b), __fmul_rn(b, c2b));
+        store1(o + (q0 + j), (r & 255u) | ((g & 255u) << 8) | ((bl & 255u) << 16) | 0xFF000000u);
+        if (++x == W) { x = 0; ++y; }
+    }
+}
+
+hipError_t launch_gradient(void *out, int W, int H, const uint8_t c1[3], const uint8_t c2[3], int vertical,
+                           hipStream_t stream) {
+    const int64_t n_px = (int64_t)W * H;
+    if (n_px <= 0) return hipSuccess;
+    const int64_t threads = (n_px + kLaneNPx - 1) / kLaneNPx;
+    hipLaunchKernelGGL(gradient_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<uint32_t *>(out), W, H, (float)c1[0], (float)c1[1], (float)c1[2], (float)c2[0],
+                       (float)c2[1], (float)c2[2], vertical);
+    return hipGetLastError();
 }
 
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream) {

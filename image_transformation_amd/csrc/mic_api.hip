@@ -945,6 +945,15 @@ extern "C" int mic_fill_solid(mic_ctx *ctx, void *out_dev, int32_t width, int32_
     return MIC_OK;
 }
 
+extern "C" int mic_fill_gradient(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height, const uint8_t c1[3],
+                                 const uint8_t c2[3], int vertical, void *stream_v) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    if (!out_dev || !c1 || !c2 || width <= 0 || height <= 0 || width > kMaxDim || height > kMaxDim)
+        return fail(MIC_ERR_INVALID, "mic_fill_gradient: bad arguments");
+    HIP_TRY(launch_gradient(out_dev, width, height, c1, c2, vertical ? 1 : 0, static_cast<hipStream_t>(stream_v)));
+    return MIC_OK;
+}
+
 extern "C" int mic_thumbnail_size(int32_t w, int32_t h, int32_t req_w, int32_t req_h, int32_t *out_w,
                                   int32_t *out_h) {
     if (!out_w || !out_h || w <= 0 || h <= 0 || req_w <= 0 || req_h <= 0)

@@ -142,6 +142,12 @@ int mic_median_rgb_dev(mic_ctx *ctx, const void *rgba_dev, int32_t width, int32_
 int mic_fill_solid(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height,
                    const uint8_t rgba[4], void *stream);
 
+/* fill_gradient's pixel loop (background_resizing.py:80-94, uncalled in the reference today): a
+ * linear gradient c1 -> c2 along x (vertical = 0) or y (vertical = 1), float32 arithmetic and uint8
+ * truncation exactly as NumPy evaluates it there; alpha 255.                                  */
+int mic_fill_gradient(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height, const uint8_t c1[3],
+                      const uint8_t c2[3], int vertical, void *stream);
+
 /* ---- helpers ----------------------------------------------------------------------------- */
 /* Pillow Image.thumbnail size rule (macro_placement_test.py:194). */
 int mic_thumbnail_size(int32_t w, int32_t h, int32_t req_w, int32_t req_h, int32_t *out_w,

@@ -192,6 +192,37 @@ def fill_solid(size: Tuple[int, int], rgba: Sequence[int]) -> np.ndarray:
     return out
 
 
+def edge_strip_medians(rgba: np.ndarray, strip_px: int = 8):
+    """background_resizing.py:36-57: medians of the left, right, top, bottom edge strips."""
+    a = _rgba(rgba)
+    h, w = a.shape[:2]
+    return (median_rgb(a[:, :min(strip_px, w)]), median_rgb(a[:, max(0, w - strip_px):]),
+            median_rgb(a[:min(strip_px, h)]), median_rgb(a[max(0, h - strip_px):]))
+
+
+def fill_gradient(rgba: np.ndarray, size: Tuple[int, int]) -> np.ndarray:
+    """background_resizing.py:60-98 restated with the same NumPy float32 semantics: t is a Python
+    float, (1 - t) and t are cast to float32 by the float32 colour arrays, products and sum are
+    float32, astype(uint8) truncates."""
+    left, right, top, bottom = edge_strip_medians(rgba)
+    var = lambda p, q: float(sum((int(p[i]) - int(q[i])) ** 2 for i in range(3)))  # noqa: E731
+    W, H = int(size[0]), int(size[1])
+    out = np.zeros((H, W, 4), np.uint8)
+    horizontal = var(left, right) <= var(top, bottom)
+    c1 = np.array(left if horizontal else top, dtype=np.float32)
+    c2 = np.array(right if horizontal else bottom, dtype=np.float32)
+    n = W if horizontal else H
+    for i in range(n):
+        t = i / max(1, n - 1)
+        rgb = (np.float32(1 - t) * c1 + np.float32(t) * c2).astype(np.uint8)
+        if horizontal:
+            out[:, i, :3] = rgb
+        else:
+            out[i, :, :3] = rgb
+    out[:, :, 3] = 255
+    return out
+
+
 def thumbnail_size(size: Tuple[int, int], req: Tuple[int, int] = (256, 256)) -> Tuple[int, int]:
     ow, oh = ctypes.c_int(), ctypes.c_int()
     lib().orc_thumbnail_size(int(size[0]), int(size[1]), int(req[0]), int(req[1]),

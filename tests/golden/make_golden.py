@@ -320,12 +320,51 @@ def gen_big_hashes():
     dump_json("big_hashes.json", {"meta": META, "cases": rows})
 
 
+def gen_gradient():
+    """background_resizing.fill_gradient / _edge_strip_median_colors (dead code in the reference today,
+    SURVEY.md section 8f row 3) on the two bundles and two small synthetic backgrounds."""
+    rows, arrays = [], {}
+    gdir = os.path.join(HERE, "gradients")
+    os.makedirs(gdir, exist_ok=True)
+    rng = np.random.default_rng(60_000)
+    synth = {}
+    a = rng.integers(0, 256, (30, 41, 4), dtype=np.uint8)
+    a[:, :20, :3] //= 4                      # dark left, bright right -> strong horizontal difference
+    a[::3, ::2, 3] = 0
+    synth["synth_lr"] = a
+    b = rng.integers(0, 256, (37, 26, 4), dtype=np.uint8)
+    b[:12, :, :3] = (b[:12, :, :3] // 8) + 200   # bright top
+    b[:, :, 3] = np.where(rng.random((37, 26)) < 0.3, 0, 255)
+    synth["synth_tb"] = b
+    c = rng.integers(0, 256, (5, 6, 4), dtype=np.uint8)  # smaller than the 8-px strips
+    c[:, :, 3] = 0                                        # fully transparent: all-pixels fallback
+    synth["synth_tiny_transparent"] = c
+    paths = {}
+    for name, arr in synth.items():
+        pth = os.path.join(gdir, name + ".png")
+        to_img(arr).save(pth)
+        paths[name] = pth
+    for bnd in cases.BUNDLES:
+        paths[bnd] = os.path.join(REF, "output", bnd, "background.png")
+    for name, pth in paths.items():
+        strips = ref_bg._edge_strip_median_colors(ref_bg._load_background_rgba(pth))
+        for size in [(97, 33), (64, 200), (1, 1), (640, 360)]:
+            out = to_arr(ref_bg.fill_gradient(pth, size))
+            key = f"{name}_{size[0]}x{size[1]}"
+            rows.append({"name": key, "background": name, "size": list(size),
+                         "strips": [list(map(int, s_)) for s_ in strips], "sha16": cases.sha16(out)})
+            if size[0] * size[1] < 20000:
+                arrays[key] = out
+    np.savez_compressed(os.path.join(HERE, "gradient.npz"), **arrays)
+    dump_json("gradient.json", {"meta": META, "cases": rows})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["bundles_copy", "canvas", "flex", "composite", "resize", "median", "bundles",
-                             "contact", "big"]
+                             "contact", "big", "gradient"]
     steps = {"bundles_copy": copy_bundles, "canvas": gen_canvas_sizes, "flex": gen_flex,
              "composite": gen_composite, "resize": gen_resize, "median": gen_median, "bundles": gen_bundles,
-             "contact": gen_contact_sheets, "big": gen_big_hashes}
+             "contact": gen_contact_sheets, "big": gen_big_hashes, "gradient": gen_gradient}
     for w in which:
         print("==", w, flush=True)
         steps[w]()
