@@ -149,3 +149,37 @@ def test_agentic_compositor_node_pixels(golden_dir):
     bad[2] = PlacementState(2, "o2", 0, 0, pls[2].width - 1, pls[2].height)
     with pytest.raises(ValueError, match="scaling objects is not permitted"):
         composite_placements(np.zeros((1, 1, 4)), objects, bad)
+
+
+# ------------------------------------------------------------------------------------------ run_macro_only harness
+@pytest.mark.gpu
+def test_run_layouts_harness_matches_reference_goldens(golden_dir, tmp_path):
+    """compute_canvas_size -> contact sheet -> fill_solid -> [flex -> place -> clamp -> composite] x 3 with
+    canned Flex JSONs (SURVEY.md section 8c harness row): iteration 0 is the App. A.6 single-column layout
+    whose reference output is a committed fixture; artifacts use the reference's tree and names."""
+    from image_transformation_amd.pipeline import run_layouts
+    with open(os.path.join(golden_dir, "bundles.json"), encoding="utf-8") as f:
+        rows = {r["name"]: r for r in json.load(f)["cases"]}
+    with open(os.path.join(golden_dir, "flex.json"), encoding="utf-8") as f:
+        kat = {c["name"]: c for c in json.load(f)["kat"]}
+    arrays = np.load(os.path.join(golden_dir, "bundles.npz"))
+    base = os.path.join(cases.BUNDLE_DIR, "squarespace")
+    layouts = [rows["squarespace_1x1"]["layout"], kat["nested_row_opts"]["layout"], kat["root_row_overflow"]["layout"]]
+    res = run_layouts(base, "1:1", layouts, output_root=str(tmp_path))
+    assert res["canvas_size"] == (492, 492) and res["background_rgba"] == (220, 238, 245, 255)
+    assert np.array_equal(np.array(res["drafts"][0]), arrays["squarespace_1x1"])
+    assert [p["box"] for p in res["placements"][1]] == [p["box"] for p in kat["nested_row_opts"]["clamped"]]
+    assert [p["box"] for p in res["placements"][2]] == [p["box"] for p in kat["root_row_overflow"]["clamped"]]
+    out = os.path.join(str(tmp_path), "squarespace")
+    for i in range(3):
+        assert os.path.exists(os.path.join(out, f"iteration_{i:02d}", "final_product", f"draft_macro_iter_{i:02d}.png"))
+        with open(os.path.join(out, f"iteration_{i:02d}", "layout_json", f"layout_macro_iter_{i:02d}.json")) as f:
+            lj = json.load(f)
+        assert lj["canvas"] == {"width": 492, "height": 492, "margin": 0.05, "align": "center"}
+        assert [p["name"] for p in lj["placements"]] and all("box" in p and "cell" in p for p in lj["placements"])
+    from PIL import Image
+    saved = np.array(Image.open(os.path.join(out, "iteration_00", "final_product", "draft_macro_iter_00.png")).convert("RGBA"))
+    assert np.array_equal(saved, arrays["squarespace_1x1"])
+    assert os.path.exists(os.path.join(out, "iteration_00", "vlm_input_image", "contact_sheet.png"))
+    canvas_png = np.array(Image.open(os.path.join(out, "iteration_00", "vlm_input_image", "canvas.png")).convert("RGBA"))
+    assert canvas_png.shape == (492, 492, 4) and (canvas_png == np.array([220, 238, 245, 255], np.uint8)).all()
