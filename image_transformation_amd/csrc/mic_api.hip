@@ -705,8 +705,9 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     }
     if (int rc = adopt_stream(ctx, stream)) return rc;
     int max_pages = 0;
+    P->ordered = P->jobs;  // this run's copy: the plan keeps the caller's own out_dev untouched
     for (int ji = 0; ji < n_jobs; ++ji) {
-        Job &d = P->jobs[(size_t)ji];
+        Job &d = P->ordered[(size_t)ji];
         if (outs) d.out = reinterpret_cast<uint64_t>(outs[ji]);
         if (!d.out) return fail(MIC_ERR_INVALID, "job %d: null output canvas", ji);
         if (d.out == d.bg) return fail(MIC_ERR_INVALID, "job %d: output aliases the background", ji);
@@ -724,7 +725,6 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         const bool solid = d.bg == 0 && (d.bg_rgba >> 24) == 255u;
         return (solid ? 0 : 2) + (aligned ? 0 : 1);
     };
-    P->ordered = P->jobs;
     std::stable_sort(P->ordered.begin(), P->ordered.end(),
                      [&](const Job &a, const Job &b) { return job_class(a) < job_class(b); });
     int class_end[3] = {0, 0, 0};

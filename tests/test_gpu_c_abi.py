@@ -1,0 +1,140 @@
+"""The C ABI used directly (no image_transformation_amd.compositor in between), the way INTEGRATION.md
+section 2 shows a foreign binding would: mic_create -> mic_atlas_create (host pointers, atlas-owned
+device blob) -> mic_composite_batch / mic_plan_* / mic_resize / mic_median_rgb / mic_fill_solid ->
+compare with the oracle.  Also the error contract: negative status + mic_last_error, no crash."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import cases  # noqa: E402
+import oracle  # noqa: E402
+
+P = ctypes.c_void_p
+U8P = ctypes.POINTER(ctypes.c_uint8)
+
+
+@pytest.fixture(scope="module")
+def abi():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need an MI355X")
+    from image_transformation_amd import _native
+    lib = _native.lib()
+    ctx = P()
+    assert lib.mic_create(torch.cuda.current_device(), ctypes.byref(ctx)) == 0, lib.mic_last_error()
+    yield lib, ctx, _native
+    assert lib.mic_destroy(ctx) == 0
+
+
+def _stream():
+    import torch
+    return P(torch.cuda.current_stream().cuda_stream)
+
+
+def _make_atlas(lib, ctx, objs):
+    ids = (ctypes.c_int32 * len(objs))(*objs.keys())
+    ws = (ctypes.c_int32 * len(objs))(*[a.shape[1] for a in objs.values()])
+    hs = (ctypes.c_int32 * len(objs))(*[a.shape[0] for a in objs.values()])
+    keep = [np.ascontiguousarray(a) for a in objs.values()]
+    ptrs = (P * len(objs))(*[a.ctypes.data for a in keep])  # const uint8_t *const *rgba_host
+    atlas = P()
+    assert lib.mic_atlas_create(ctx, len(objs), ids, ws, hs, ptrs, ctypes.byref(atlas)) == 0, lib.mic_last_error()
+    return atlas
+
+
+def test_raw_abi_composite_plan_resize_median(abi):
+    import torch
+    lib, ctx, nat = abi
+    rng = np.random.default_rng(4242)
+    objs = {7: cases.synthetic.make_cutout(rng, 61, 45, "soft"), 3: cases.synthetic.make_cutout(rng, 33, 80, "binary")}
+    atlas = _make_atlas(lib, ctx, objs)
+    assert lib.mic_atlas_count(atlas) == 2
+    w, h, ptr = ctypes.c_int32(), ctypes.c_int32(), P()
+    assert lib.mic_atlas_lookup(atlas, 3, ctypes.byref(w), ctypes.byref(h), ctypes.byref(ptr)) == 0
+    assert (w.value, h.value) == (33, 80) and ptr.value
+    assert lib.mic_atlas_lookup(atlas, 99, None, None, None) < 0 and b"not in the atlas" in lib.mic_last_error()
+    blob, nbytes = P(), ctypes.c_size_t()
+    assert lib.mic_atlas_device_blob(atlas, ctypes.byref(blob), ctypes.byref(nbytes)) == 0 and nbytes.value > 61 * 45 * 4
+
+    W, H = 333, 207  # W % 4 != 0: the unaligned kernel class
+    placements = [{"object_id": 7, "box": [-10, 5, 51, 50]}, {"object_id": 3, "box": [300, 150, 333 + 20, 150 + 100]},
+                  {"object_id": 7, "box": [100, 100, 222, 190]}, {"object_id": 5, "box": [0, 0, 9, 9]}]
+    pl = (nat.Placement * len(placements))()
+    for i, p in enumerate(placements):
+        pl[i].atlas, pl[i].object_id = 0, p["object_id"]
+        for k in range(4):
+            pl[i].box[k] = p["box"][k]
+    out = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+    job = nat.Job()
+    job.width, job.height, job.bg_dev = W, H, None
+    for k, v in enumerate((9, 200, 33, 255)):
+        job.bg_rgba[k] = v
+    job.n_placements, job.placements, job.out_dev = len(placements), pl, out.data_ptr()
+    atl = (P * 1)(atlas)
+    assert lib.mic_composite_batch(ctx, 1, atl, 1, ctypes.byref(job), 0, _stream()) == 0, lib.mic_last_error()
+    bg = oracle.fill_solid((W, H), (9, 200, 33, 255))
+    want = oracle.composite(bg, objs, placements)
+    assert np.array_equal(out.cpu().numpy(), want)
+    st = nat.Stats()
+    assert lib.mic_last_stats(ctx, ctypes.byref(st)) == 0
+    assert st.skipped_placements == 1 and st.resampled_layers == 2 and st.identity_layers == 1
+
+    # the same through a persistent plan, run twice into different canvases
+    plan = P()
+    job.out_dev = None
+    assert lib.mic_plan_create(ctx, 1, atl, 1, ctypes.byref(job), 0, ctypes.byref(plan)) == 0, lib.mic_last_error()
+    for _ in range(2):
+        o2 = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        outs = (P * 1)(o2.data_ptr())
+        assert lib.mic_plan_run(plan, outs, _stream()) == 0, lib.mic_last_error()
+        assert np.array_equal(o2.cpu().numpy(), want)
+    assert lib.mic_plan_run(plan, None, _stream()) < 0 and b"null output" in lib.mic_last_error()
+    assert lib.mic_plan_destroy(plan) == 0
+
+    # resize, median, fill
+    src = torch.from_numpy(objs[7]).cuda()
+    dst = torch.empty((20, 90, 4), dtype=torch.uint8, device="cuda")
+    assert lib.mic_resize(ctx, P(src.data_ptr()), 61, 45, P(dst.data_ptr()), 90, 20, 0, _stream()) == 0
+    assert np.array_equal(dst.cpu().numpy(), oracle.resize(objs[7], (90, 20)))
+    rgb = (ctypes.c_uint8 * 3)()
+    assert lib.mic_median_rgb(ctx, P(out.data_ptr()), W, H, rgb, _stream()) == 0
+    assert tuple(rgb) == oracle.median_rgb(want)
+    col = (ctypes.c_uint8 * 4)(1, 2, 3, 4)
+    assert lib.mic_fill_solid(ctx, P(out.data_ptr()), W, H, col, _stream()) == 0
+    assert (out.cpu().numpy() == np.array([1, 2, 3, 4], np.uint8)).all()
+    assert lib.mic_sync(ctx, _stream()) == 0
+    assert lib.mic_atlas_destroy(atlas) == 0
+
+
+def test_raw_abi_rejects_bad_arguments(abi):
+    import torch
+    lib, ctx, nat = abi
+    objs = {1: np.zeros((4, 4, 4), np.uint8)}
+    atlas = _make_atlas(lib, ctx, objs)
+    atl = (P * 1)(atlas)
+    out = torch.empty((8, 8, 4), dtype=torch.uint8, device="cuda")
+    job = nat.Job()
+    job.width, job.height, job.out_dev, job.n_placements = 8, 8, out.data_ptr(), 0
+    assert lib.mic_composite_batch(ctx, 1, atl, 1, ctypes.byref(job), 7, _stream()) < 0 and b"filter" in lib.mic_last_error()
+    job.width = 0
+    assert lib.mic_composite_batch(ctx, 1, atl, 1, ctypes.byref(job), 0, _stream()) < 0 and b"canvas size" in lib.mic_last_error()
+    job.width, job.bg_dev = 8, out.data_ptr()
+    assert lib.mic_composite_batch(ctx, 1, atl, 1, ctypes.byref(job), 0, _stream()) < 0 and b"aliases" in lib.mic_last_error()
+    job.bg_dev = None
+    pl = (nat.Placement * 1)()
+    pl[0].atlas, pl[0].object_id = 3, 1
+    job.n_placements, job.placements = 1, pl
+    assert lib.mic_composite_batch(ctx, 1, atl, 1, ctypes.byref(job), 0, _stream()) < 0 and b"atlas index" in lib.mic_last_error()
+    pl[0].atlas = 0
+    pl[0].box[0], pl[0].box[1], pl[0].box[2], pl[0].box[3] = 0, 0, 70000, 4
+    assert lib.mic_composite_batch(ctx, 1, atl, 1, ctypes.byref(job), 0, _stream()) < 0 and b"too large" in lib.mic_last_error()
+    assert lib.mic_composite_batch(None, 1, atl, 1, ctypes.byref(job), 0, _stream()) < 0
+    # a corrupt blob is refused, not dereferenced
+    junk = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    bad = P()
+    assert lib.mic_atlas_from_device_blob(ctx, P(junk.data_ptr()), 4096, None, ctypes.byref(bad)) < 0
+    assert b"magic" in lib.mic_last_error()
+    assert lib.mic_atlas_destroy(atlas) == 0
