@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmic.so")
 SOURCES = ["mic_api.hip", "kernels_composite.hip", "kernels_resample.hip", "kernels_median.hip",
-           "resample_coeffs.cpp"]
-HEADERS = ["mic_internal.h", "resample_coeffs.h", os.path.join("..", "..", "include", "mic.h")]
+           "resample_coeffs.cpp", "flex_place.cpp"]
+HEADERS = ["mic_internal.h", "resample_coeffs.h", "flex_place.h", os.path.join("..", "..", "include", "mic.h")]
 ARCH = "gfx950"
 
 

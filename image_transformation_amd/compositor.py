@@ -176,8 +176,11 @@ class ObjectImages(dict):
             self._atlas = Atlas(self, device)
         return self._atlas
 
+    _native_table = None  # (ids, widths, heights) arrays cached by flex.native_boxes
+
     def _touch(self):
         self._atlas = None
+        self._native_table = None
 
     def __setitem__(self, k, v):
         self._touch()
@@ -397,6 +400,19 @@ def composite(background_img: Image.Image, object_images: Mapping[int, Image.Ima
     return _to_pil(out)
 
 
+def _layout_rows(layout_json: Any, images: Mapping[int, Any], atlas: "Atlas", size: Tuple[int, int]):
+    """layout (Flex tree as dict or JSON text, {"placements": [...]}, or a list) -> coerced rows
+    [(object_id, x1, y1, x2, y2)] for ids the atlas knows.  Flex trees go through the native placer
+    (mic_flex_place) when it can mirror them, otherwise through flex.py -- same boxes either way,
+    and flex.py is what raises the reference's errors for malformed trees."""
+    native = flex.native_boxes(layout_json, images, size)
+    if native is not None:
+        return [r for r in native if r[0] in atlas]
+    if isinstance(layout_json, (str, bytes)):
+        layout_json = json.loads(layout_json)
+    return coerce_placements(atlas, flex.layout_to_placements(layout_json, images, size))
+
+
 def _canvas_size(canvas) -> Tuple[int, int]:
     if isinstance(canvas, (SolidCanvas, Image.Image)):
         return canvas.size
@@ -414,8 +430,7 @@ def render(layout_json: Any, objects: Mapping[int, Any], canvas: Any, *, filter:
     canvas: an RGBA PIL image, a SolidCanvas, or a device uint8 (H, W, 4) tensor."""
     atlas = _as_atlas(objects)
     size = _canvas_size(canvas)
-    placements = flex.layout_to_placements(layout_json, objects if not isinstance(objects, Atlas) else atlas, size)
-    rows = coerce_placements(atlas, placements)
+    rows = _layout_rows(layout_json, objects if not isinstance(objects, Atlas) else atlas, atlas, size)
     if isinstance(canvas, Image.Image):
         if not rows and not as_tensor:
             return canvas.copy()
@@ -429,8 +444,5 @@ def render_batch(layouts: Sequence[Any], objects: Mapping[int, Any], canvases: S
     """One launch for a batch of variants of one bundle (BASELINE.json configs[3]): layouts[i] onto
     canvases[i].  Returns device tensors; nothing is copied to the host."""
     atlas = _as_atlas(objects)
-    rows = []
-    for layout, cv in zip(layouts, canvases):
-        pl = flex.layout_to_placements(layout, atlas, _canvas_size(cv))
-        rows.append(coerce_placements(atlas, pl))
+    rows = [_layout_rows(layout, atlas, atlas, _canvas_size(cv)) for layout, cv in zip(layouts, canvases)]
     return composite_device(atlas, list(canvases), rows, outs=outs, filter=filter)

@@ -17,6 +17,7 @@
 
 #include "../../include/mic.h"  // declares mic_plan, mic_ctx, mic_atlas
 #include "mic_internal.h"
+#include "flex_place.h"
 #include "resample_coeffs.h"
 
 using namespace mic;
@@ -951,6 +952,28 @@ extern "C" int mic_fill_gradient(mic_ctx *ctx, void *out_dev, int32_t width, int
     if (!out_dev || !c1 || !c2 || width <= 0 || height <= 0 || width > kMaxDim || height > kMaxDim)
         return fail(MIC_ERR_INVALID, "mic_fill_gradient: bad arguments");
     HIP_TRY(launch_gradient(out_dev, width, height, c1, c2, vertical ? 1 : 0, static_cast<hipStream_t>(stream_v)));
+    return MIC_OK;
+}
+
+extern "C" int mic_flex_place(const char *layout_json, size_t len, int n_objects, const int32_t *ids,
+                              const int32_t *widths, const int32_t *heights, int32_t canvas_w, int32_t canvas_h,
+                              int32_t capacity, int32_t *out_ids, int32_t *out_boxes, int32_t *out_count) {
+    if (!layout_json || !out_count || n_objects < 0 || (n_objects > 0 && (!ids || !widths || !heights)) ||
+        capacity < 0 || (capacity > 0 && (!out_ids || !out_boxes)) || canvas_w <= 0 || canvas_h <= 0)
+        return fail(MIC_ERR_INVALID, "mic_flex_place: bad arguments");
+    std::vector<int32_t> oi, ob;
+    std::string err;
+    const int rc = flex_place(layout_json, len, n_objects, ids, widths, heights, canvas_w, canvas_h, &oi, &ob, &err);
+    if (rc == kFlexMalformed) return fail(MIC_ERR_FORMAT, "mic_flex_place: %s", err.c_str());
+    if (rc == kFlexUnsupported)
+        return fail(MIC_ERR_UNSUPPORTED, "mic_flex_place: layout uses features only the Python placer mirrors");
+    *out_count = (int32_t)oi.size();
+    if ((int32_t)oi.size() > capacity)
+        return fail(MIC_ERR_INVALID, "mic_flex_place: %zu placements, capacity %d", oi.size(), capacity);
+    if (!oi.empty()) {
+        memcpy(out_ids, oi.data(), oi.size() * sizeof(int32_t));
+        memcpy(out_boxes, ob.data(), ob.size() * sizeof(int32_t));
+    }
     return MIC_OK;
 }
 

@@ -328,6 +328,80 @@ def clamp_boxes(placements: List[dict], canvas_size: Tuple[int, int]) -> None:
         p["box"] = [int(x1), int(y1), int(x1 + w), int(y1 + h)]
 
 
+def native_boxes(layout: Any, images: Mapping[int, Any],
+                 canvas_size: Tuple[int, int]) -> Optional[List[Tuple[int, int, int, int, int]]]:
+    """Placement boxes [(object_id, x1, y1, x2, y2), ...] from libmic's native placer
+    (mic_flex_place, csrc/flex_place.cpp), or None when the layout is not a {"root": ...} tree or
+    uses something the native placer leaves to this module (then call layout_to_placements, which
+    also raises the reference's errors).  `layout` may be the JSON text itself (a VLM reply) or the
+    parsed dict.  Host-only: no GPU is touched."""
+    import ctypes
+    import json
+
+    import numpy as np
+
+    from . import _native
+
+    if isinstance(layout, (bytes, str)):
+        text = layout.encode("utf-8") if isinstance(layout, str) else layout
+    elif isinstance(layout, dict) and "root" in layout:
+        try:
+            text = json.dumps(layout, separators=(",", ":")).encode("utf-8")
+        except (TypeError, ValueError):
+            return None
+    else:
+        return None
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    tab = getattr(images, "_native_table", None)
+    if tab is None:
+        ids, ws, hs = [], [], []
+        for oid in images:
+            size = _size_of(images, oid)
+            if not isinstance(oid, int) or isinstance(oid, bool) or size is None:
+                return None
+            ids.append(oid)
+            ws.append(size[0])
+            hs.append(size[1])
+        arrs = (np.asarray(ids, np.int32), np.asarray(ws, np.int32), np.asarray(hs, np.int32))
+        tab = (len(ids), arrs, tuple(a.ctypes.data_as(i32p) for a in arrs))
+        try:
+            images._native_table = tab  # Atlas / ObjectImages keep it; plain dicts recompute
+        except AttributeError:
+            pass
+    n_obj, _, (ids_p, ws_p, hs_p) = tab
+    cap = 4 * n_obj + 64
+    lib = _native.lib()
+    while True:
+        buf = _scratch(cap)
+        n = ctypes.c_int32(-1)
+        rc = lib.mic_flex_place(text, len(text), n_obj, ids_p, ws_p, hs_p, int(canvas_size[0]), int(canvas_size[1]),
+                                cap, buf[2], buf[3], ctypes.byref(n))
+        if rc == 0:
+            k = n.value
+            o, b = buf[0][:k].tolist(), buf[1][:4 * k].tolist()
+            return [(o[i], b[4 * i], b[4 * i + 1], b[4 * i + 2], b[4 * i + 3]) for i in range(k)]
+        if n.value > cap:  # a layout that mentions objects many times over
+            cap = n.value
+            continue
+        return None  # unsupported or malformed: the Python placer decides what that means
+
+
+_scratch_buf: List[Any] = []
+
+
+def _scratch(cap: int):
+    """Reusable output arrays (ids, boxes) and their ctypes pointers for native_boxes."""
+    import ctypes
+
+    import numpy as np
+
+    if not _scratch_buf or len(_scratch_buf[0]) < cap:
+        i32p = ctypes.POINTER(ctypes.c_int32)
+        ids, boxes = np.empty(cap, np.int32), np.empty(4 * cap, np.int32)
+        _scratch_buf[:] = [ids, boxes, ids.ctypes.data_as(i32p), boxes.ctypes.data_as(i32p)]
+    return _scratch_buf
+
+
 def layout_to_placements(layout: Any, images: Mapping[int, Any],
                          canvas_size: Tuple[int, int]) -> List[dict]:
     """layout_json -> placements, the way run_macro_only does it before composite()

@@ -41,7 +41,8 @@ enum mic_status {
     MIC_ERR_HIP = -2,       /* a HIP runtime call failed (message has details) */
     MIC_ERR_NOMEM = -3,     /* host or device allocation failed                */
     MIC_ERR_NODEVICE = -4,  /* no usable gfx950 device                         */
-    MIC_ERR_FORMAT = -5     /* malformed atlas blob                            */
+    MIC_ERR_FORMAT = -5,    /* malformed atlas blob / layout JSON              */
+    MIC_ERR_UNSUPPORTED = -6 /* valid input this native path leaves to the caller */
 };
 
 enum mic_filter {
@@ -147,6 +148,19 @@ int mic_fill_solid(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height,
  * truncation exactly as NumPy evaluates it there; alpha 255.                                  */
 int mic_fill_gradient(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height, const uint8_t c1[3],
                       const uint8_t c2[3], int vertical, void *stream);
+
+/* ---- layout: the integer half of render() -------------------------------------------------
+ * Flex-DSL JSON text ({"root": {...}}) + cutout sizes + canvas size -> object ids and clamped boxes
+ * in depth-first order: _measure_flex_node / _place_flex_container / _clamp_boxes_to_canvas
+ * (macro_placement_test.py:637-964) for the well-formed subset of the DSL.  Host-only, no device.
+ * MIC_ERR_UNSUPPORTED: the tree uses something whose behaviour hangs on Python's type rules or on
+ * the object-level validators (pin / offset_px / stick_to, non-integer numbers, ...); the Python
+ * binding then runs its own mirror (flex.py), which returns the result or raises the reference's
+ * error.  MIC_ERR_FORMAT: not JSON.  On success *out_count placements were written (capacity is the
+ * room in out_ids / out_boxes (4 per placement); too small -> MIC_ERR_INVALID with *out_count set). */
+int mic_flex_place(const char *layout_json, size_t len, int n_objects, const int32_t *ids,
+                   const int32_t *widths, const int32_t *heights, int32_t canvas_w, int32_t canvas_h,
+                   int32_t capacity, int32_t *out_ids, int32_t *out_boxes_xyxy, int32_t *out_count);
 
 /* ---- helpers ----------------------------------------------------------------------------- */
 /* Pillow Image.thumbnail size rule (macro_placement_test.py:194). */

@@ -54,6 +54,34 @@ def test_nested_known_answers(flex_golden):
     assert boxes("object_pin_offset_stick") == boxes("nested")  # pins/offsets/sticks are arithmetic no-ops
 
 
+def test_native_placer_matches_reference_or_declines(flex_golden):
+    """mic_flex_place (csrc/flex_place.cpp): whenever it accepts a tree its boxes are the reference's
+    (after clamp); trees that hang on Python type rules / object validators are declined (None)."""
+    import json as _json
+    accepted = 0
+    for case in flex_golden["cases"] + flex_golden["kat"]:
+        sizes = {int(k): tuple(v) for k, v in case["sizes"].items()}
+        want = [(int(p["object_id"]), *p["box"]) for p in case["clamped"]]
+        got = flex.native_boxes(case["layout"], sizes, tuple(case["canvas"]))
+        if got is None:
+            continue
+        accepted += 1
+        assert got == want, case["name"]
+        # the JSON text form (a VLM reply) gives the same answer, whitespace and key order aside
+        text = _json.dumps(case["layout"], indent=2, sort_keys=True)
+        assert flex.native_boxes(text, sizes, tuple(case["canvas"])) == want, case["name"]
+    assert accepted >= 0.6 * (len(flex_golden["cases"]) + len(flex_golden["kat"])), accepted
+    sq = {k: tuple(v) for k, v in cases.SQUARESPACE_SIZES.items()}
+    for row in flex_golden["errors"]:  # every malformed object field is left to flex.py (which raises)
+        node = dict({"object_id": 2}, **row["fields"])
+        layout = {"root": {"type": "flex", "direction": "row", "children": [{"object_id": 1}, node]}}
+        if row["error"] is not None:
+            assert flex.native_boxes(layout, sq, (492, 492)) is None, row["fields"]
+    assert flex.native_boxes("{not json", sq, (492, 492)) is None
+    assert flex.native_boxes({"placements": []}, sq, (492, 492)) is None
+    assert flex.native_boxes('{"root": {"direction": "r\\u006fw", "children": []}}', sq, (9, 9)) is None
+
+
 def test_layout_to_placements_forms(flex_golden):
     case = flex_golden["kat"][1]
     sizes = {int(k): tuple(v) for k, v in case["sizes"].items()}
