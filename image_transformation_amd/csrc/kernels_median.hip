@@ -6,11 +6,24 @@
 // gives the order statistics (n-1)//2 and n//2 whose mean np.median returns.  One streaming read
 // of the image (4 B/px): HBM-bound.
 //
-// Histogram kernel: per-wavefront private LDS histograms.  Backgrounds are mostly flat, so within
-// a wave all lanes often hit the same bin; instead of letting 64 same-address LDS atomics serialise,
-// the wave checks for that case with readlane/__ballot and lets one lane add the population count.
-// Otherwise (noisy regions, mostly distinct bins) every lane issues its own LDS atomic.  Per-block
-// totals are flushed with one global atomic per non-empty bin.
+// ONE launch.  Every pixel goes into one of two histogram sets, keyed by alpha > 0 / alpha == 0.
+// The reference's "all pixels" fallback only triggers when no pixel has alpha > 0 -- and then the
+// alpha == 0 set IS all pixels -- so the two sets answer both cases from a single pass.  The block
+// that retires last (device-scope ticket) runs the 256-bin scan + select and then re-zeroes the
+// scratch, so the next call needs neither a memset nor a second kernel.
+//
+// Shape: at most 512 blocks of 16 waves (two per CU fill every wave slot of the chip), one LDS
+// histogram per block (8 bank-interleaved replicas, 48 KiB).  A wave owns 4 KiB of the image per trip and issues its four 16-byte
+// loads per lane back to back, unconditionally (a load under a branch makes hipcc wait for it
+// before issuing the next); only the single ragged trip at the end of the image goes through a
+// guarded per-pixel path.  Few, large blocks also keep the two per-block costs small: the flush of
+// non-empty bins (same-address global atomics from every block) and the agent-scope release on the
+// ticket.
+//
+// Backgrounds are mostly flat, so within a wave all 256 pixels of a chunk often hit the same bin;
+// instead of letting 256 same-address LDS atomics serialise, the wave tests each channel for that
+// case with readfirstlane/__ballot and lets one lane add the population count.  Otherwise (noisy
+// regions, mostly distinct bins) every lane issues its own LDS atomics.
 #include <algorithm>
 
 #include "mic_internal.h"
@@ -19,118 +32,109 @@ namespace mic {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kHistWaves = 4;
+constexpr int kHistWaves = 16;
+constexpr int kChunks = 4;                      // 16-byte loads a lane keeps in flight per trip
+constexpr size_t kTripPx = (size_t)256 * kChunks;  // pixels one wave takes per trip (4 KiB)
+constexpr unsigned kMaxBlocks = 512;
+// LDS histogram replicas, interleaved so the kCopies words of one bin sit in kCopies different banks:
+// word = bin_index * kCopies + (lane & (kCopies - 1)).  64 lanes hitting one bin serialise 64/kCopies
+// deep instead of 64.
+constexpr int kCopies = 8;
 
-// hist layout (uint32): [set][channel][256], set 0 = alpha > 0, set 1 = all pixels;
-// then counts[2] at kCountOff.
-constexpr int kCountOff = 2 * 3 * 256;
+// scratch layout (uint32): [set][channel][256], set 0 = alpha > 0, set 1 = alpha == 0;
+// then counts[2] at kCountOff and the retirement ticket at kTicketOff.  All zero between calls.
+constexpr int kSetWords = 3 * 256;
+constexpr int kCountOff = 2 * kSetWords;
+constexpr int kTicketOff = kCountOff + 2;
+static_assert(kTicketOff < (int)kMedianScratchWords, "median scratch too small");
+static_assert(kHistWaves == 16, "median_select maps 3 channels x 256 bins onto 1024 threads");
 
-__device__ __forceinline__ void wave_hist_add(uint32_t *h, uint32_t v, bool valid, int lane) {
-    // Backgrounds are mostly flat: if every participating lane of the wave holds the same value, one
-    // lane adds the population count (readfirstlane + compare + ballot); otherwise every lane issues
-    // its own LDS atomic (noise spreads over the bins, so those rarely collide).
-    const unsigned long long todo = __ballot(valid);
-    if (todo == 0) return;
-    const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t lv = (uint32_t)__builtin_amdgcn_readlane((int)v, leader);
-    if (__ballot(valid && v != lv) == 0) {
-        if (lane == leader) atomicAdd(&h[lv], (uint32_t)__popcll(todo));
-    } else if (valid) {
-        atomicAdd(&h[v], 1u);
+__device__ inline uint32_t agent_load(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One chunk: the 4 pixels each lane of the wave holds (256 consecutive pixels per wave).  ok[] marks
+// the pixels inside the image; lane 0's p[0] is always one of them.
+//
+// Same-address LDS atomics serialise, and backgrounds are mostly flat: left alone, 256 pixels of one
+// colour cost 768 serialised adds.  The budget at HBM speed is ~120 VALU instructions and ~120 LDS
+// cycles per chunk, so the remedy has to be cheap: per channel, a lane whose 4 pixels all equal the
+// leader pixel (lane 0's first) in that channel and alpha class is "flat"; flat lanes are counted
+// with one __ballot/popcount and added once by lane 0, and only the other lanes issue LDS atomics.
+// A flat chunk costs 3 adds, flat-with-detail a few lanes' worth, noise what the plain loop costs.
+template <bool FULL>
+__device__ inline void hist_chunk(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, bool ok0, bool ok1, bool ok2,
+                                  bool ok3, uint32_t *lh, int lane, uint32_t &n_opaque, uint32_t &n_clear) {
+    const uint32_t p[4] = {p0, p1, p2, p3};
+    const bool ok[4] = {ok0, ok1, ok2, ok3};
+    const uint32_t copy = (uint32_t)lane & (kCopies - 1);
+    const uint32_t lp = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);  // the leader pixel
+    const uint32_t lset = (lp >> 24) != 0u ? 0u : 1u;
+    uint32_t cls[4];  // histogram set of each pixel: 0 = alpha > 0, 1 = alpha == 0
+    uint32_t cnt = 0, clr = 0;
+    // diff: OR of (pixel ^ leader) over the lane's pixels; bit 24 is replaced by "alpha class differs
+    // from the leader's", bits 25-31 are dropped.  A ragged chunk (!FULL) takes no shortcut.
+    uint32_t diff = FULL ? 0u : ~0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cls[j] = (p[j] >> 24) != 0u ? 0u : 1u;
+        cnt += (FULL || ok[j]) ? 1u : 0u;
+        clr += (FULL || ok[j]) ? cls[j] : 0u;
+        diff |= ((p[j] ^ lp) & 0x00ffffffu) | ((cls[j] ^ lset) << 24);
+    }
+    n_opaque += cnt - clr;
+    n_clear += clr;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int sh = 8 * c;
+        const bool flat = (diff & ((255u << sh) | (1u << 24))) == 0u;
+        const unsigned long long fb = __ballot(flat);
+        if (fb != 0 && lane == 0)
+            atomicAdd(&lh[((lset * 3 + c) * 256 + ((lp >> sh) & 255u)) * kCopies], 4u * (uint32_t)__popcll(fb));
+        if (fb == ~0ull) continue;  // wave-uniform: the whole chunk is flat in this channel
+        if (!flat) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (FULL || ok[j])
+                    atomicAdd(&lh[((cls[j] * 3 + c) * 256 + ((p[j] >> sh) & 255u)) * kCopies + copy], 1u);
+        }
     }
 }
 
-// mode 0: pixels with alpha > 0.  mode 1: all pixels, skipped entirely unless counts[0] == 0.
-__global__ __launch_bounds__(64 * kHistWaves) void median_hist_kernel(
-    const uint32_t *__restrict__ px, size_t n_px, uint32_t *__restrict__ hist, int mode) {
-    if (mode == 1 && hist[kCountOff] != 0) return;
-    __shared__ uint32_t lh[kHistWaves][3][256];
-    __shared__ uint32_t lcount[kHistWaves];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < kHistWaves * 3 * 256; i += blockDim.x) (&lh[0][0][0])[i] = 0;
-    if (threadIdx.x < kHistWaves) lcount[threadIdx.x] = 0;
-    __syncthreads();
-
-    uint32_t *h0 = lh[wave][0], *h1 = lh[wave][1], *h2 = lh[wave][2];
-    uint32_t my_count = 0;
-    // wave-uniform trip count: every lane of a wave stays in the loop (ballot/readlane inside)
-    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
-    for (size_t base = ((size_t)blockIdx.x * blockDim.x + (size_t)wave * 64) * 4; base < n_px;
-         base += stride) {
-        const size_t i = base + (size_t)lane * 4;
-        uint32_t p[4];
-        bool ok[4];
-        if (i + 4 <= n_px) {
-            u32x4 v;
-            __builtin_memcpy(&v, px + i, 16);
-            p[0] = v[0]; p[1] = v[1]; p[2] = v[2]; p[3] = v[3];
-            ok[0] = ok[1] = ok[2] = ok[3] = true;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                ok[j] = i + j < n_px;
-                p[j] = ok[j] ? px[i + j] : 0u;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool take = ok[j] && (mode == 1 || (p[j] >> 24) != 0u);
-            wave_hist_add(h0, p[j] & 255u, take, lane);
-            wave_hist_add(h1, (p[j] >> 8) & 255u, take, lane);
-            wave_hist_add(h2, (p[j] >> 16) & 255u, take, lane);
-            my_count += take ? 1u : 0u;
-        }
-    }
-    // wave-level count reduction (shuffle), one LDS add per wave
-    for (int off = 32; off > 0; off >>= 1) my_count += __shfl_down(my_count, off);
-    if (lane == 0) lcount[wave] = my_count;
-    __syncthreads();
-
-    uint32_t *gh = hist + (size_t)mode * 3 * 256;
-    for (int i = threadIdx.x; i < 3 * 256; i += blockDim.x) {
-        uint32_t s = 0;
-#pragma unroll
-        for (int w = 0; w < kHistWaves; ++w) s += (&lh[w][0][0])[i];
-        if (s) atomicAdd(&gh[i], s);
-    }
-    if (threadIdx.x == 0) {
-        uint32_t s = 0;
-        for (int w = 0; w < kHistWaves; ++w) s += lcount[w];
-        if (s) atomicAdd(&hist[kCountOff + mode], s);
-    }
-}
-
-// One block: cumulative scan of each channel's 256 bins, pick order statistics (n-1)//2 and n//2,
-// write int((lo + hi) / 2) -- np.median's mean of the two middle values, truncated by int().
-__global__ __launch_bounds__(256) void median_select_kernel(const uint32_t *__restrict__ hist,
-                                                            uint32_t *__restrict__ out_rgba) {
-    __shared__ uint32_t wave_tot[4];
-    __shared__ uint32_t res[3][2];
+// Last block, 1024 threads: thread t carries bin (t & 255) of channel (t >> 8) (the fourth quarter
+// idles).  All global loads are issued up front -- they are agent-scope, a memory round trip each --
+// then one 256-bin scan per channel picks the order statistics (n-1)//2 and n//2 and thread 0 writes
+// int((lo + hi) / 2): np.median's mean of the two middle values, truncated by int().
+__device__ void median_select(const uint32_t *hist, uint32_t *out_rgba, uint32_t *wave_tot,
+                              uint32_t (*res)[2]) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int set = hist[kCountOff] != 0 ? 0 : 1;
-    const uint32_t n = hist[kCountOff + set];
-    if (n == 0) {  // empty image
+    const int c = t >> 8, bin = t & 255;
+    const bool act = c < 3;
+    const uint32_t n0 = agent_load(hist + kCountOff);
+    const uint32_t n1 = agent_load(hist + kCountOff + 1);
+    const uint32_t v0 = act ? agent_load(hist + (0 * 3 + c) * 256 + bin) : 0u;
+    const uint32_t v1 = act ? agent_load(hist + (1 * 3 + c) * 256 + bin) : 0u;
+    const uint32_t n = n0 != 0 ? n0 : n1;
+    if (n == 0) {  // empty image (block-uniform)
         if (t == 0) out_rgba[0] = 0xff000000u;
         return;
     }
+    const uint32_t v = n0 != 0 ? v0 : v1;
     const uint32_t klo = (n - 1) / 2, khi = n / 2;
-    for (int c = 0; c < 3; ++c) {
-        const uint32_t v = hist[(set * 3 + c) * 256 + t];
-        uint32_t incl = v;  // inclusive scan within the wave
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t up = __shfl_up(incl, off);
-            if (lane >= off) incl += up;
-        }
-        if (lane == 63) wave_tot[wave] = incl;
-        __syncthreads();
-        uint32_t before = 0;
-        for (int w = 0; w < wave; ++w) before += wave_tot[w];
-        incl += before;
-        const uint32_t excl = incl - v;
-        if (excl <= klo && klo < incl) res[c][0] = (uint32_t)t;
-        if (excl <= khi && khi < incl) res[c][1] = (uint32_t)t;
-        __syncthreads();
+    uint32_t incl = v;  // inclusive scan within the wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
     }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    if (act) {
+        for (int w = c * 4; w < wave; ++w) incl += wave_tot[w];
+        const uint32_t excl = incl - v;
+        if (excl <= klo && klo < incl) res[c][0] = (uint32_t)bin;
+        if (excl <= khi && khi < incl) res[c][1] = (uint32_t)bin;
+    }
+    __syncthreads();
     if (t == 0) {
         const uint32_t r = (res[0][0] + res[0][1]) >> 1;
         const uint32_t g = (res[1][0] + res[1][1]) >> 1;
@@ -139,22 +143,95 @@ __global__ __launch_bounds__(256) void median_select_kernel(const uint32_t *__re
     }
 }
 
+__global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const uint32_t *__restrict__ px, size_t n_px,
+                                                                  uint32_t *__restrict__ hist,
+                                                                  uint32_t *__restrict__ out_rgba) {
+    __shared__ uint32_t lh[2 * kSetWords * kCopies];
+    __shared__ uint32_t lcount[2];
+    __shared__ uint32_t wave_tot[kHistWaves];
+    __shared__ uint32_t res[3][2];
+    __shared__ uint32_t is_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 2 * kSetWords * kCopies; i += blockDim.x) lh[i] = 0;
+    if (threadIdx.x < 2) lcount[threadIdx.x] = 0;
+    __syncthreads();
+
+    uint32_t n_opaque = 0, n_clear = 0;
+    const size_t stride = (size_t)gridDim.x * kHistWaves * kTripPx;
+    size_t wbase = ((size_t)blockIdx.x * kHistWaves + wave) * kTripPx;
+    for (; wbase + kTripPx <= n_px; wbase += stride) {  // whole trips: wave-uniform, no guards
+        u32x4 ld[kChunks];
+#pragma unroll
+        for (int u = 0; u < kChunks; ++u)
+            __builtin_memcpy(&ld[u], px + wbase + (size_t)u * 256 + (size_t)lane * 4, 16);
+#pragma unroll
+        for (int u = 0; u < kChunks; ++u) {
+            hist_chunk<true>(ld[u][0], ld[u][1], ld[u][2], ld[u][3], true, true, true, true, lh, lane, n_opaque, n_clear);
+        }
+    }
+    if (wbase < n_px) {  // the image's ragged last trip: exactly one wave of the grid gets here
+        for (int u = 0; u < kChunks; ++u) {
+            const size_t cbase = wbase + (size_t)u * 256;
+            if (cbase >= n_px) break;
+            const size_t i = cbase + (size_t)lane * 4;
+            uint32_t p[4];
+            bool ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ok[j] = i + j < n_px;
+                p[j] = ok[j] ? px[i + j] : 0u;
+            }
+            hist_chunk<false>(p[0], p[1], p[2], p[3], ok[0], ok[1], ok[2], ok[3], lh, lane, n_opaque, n_clear);
+        }
+    }
+    // wave-level count reductions (shuffle), one LDS add per wave and set
+    for (int off = 32; off > 0; off >>= 1) {
+        n_opaque += __shfl_down(n_opaque, off);
+        n_clear += __shfl_down(n_clear, off);
+    }
+    if (lane == 0) {
+        if (n_opaque) atomicAdd(&lcount[0], n_opaque);
+        if (n_clear) atomicAdd(&lcount[1], n_clear);
+    }
+    __syncthreads();
+
+    for (int i = threadIdx.x; i < 2 * kSetWords; i += blockDim.x) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int k = 0; k < kCopies; ++k) s += lh[i * kCopies + ((k + threadIdx.x) & (kCopies - 1))];
+        if (s) atomicAdd(&hist[i], s);
+    }
+    if (threadIdx.x < 2 && lcount[threadIdx.x]) atomicAdd(&hist[kCountOff + threadIdx.x], lcount[threadIdx.x]);
+
+    // Retirement ticket.  The barrier orders every thread's histogram atomics before thread 0's
+    // agent-scope release on the ticket (release is cumulative), so the block drawing the last
+    // ticket -- after its acquire -- sees every block's contribution.  One release per block, not a
+    // fence per wave: an agent-scope fence is an L2 write-back on gfx950.
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t ticket =
+            __hip_atomic_fetch_add(hist + kTicketOff, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = ticket == gridDim.x - 1 ? 1u : 0u;
+        if (is_last) __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    median_select(hist, out_rgba, wave_tot, res);
+    __syncthreads();
+    // leave the scratch zeroed for the next call on this context
+    for (int i = threadIdx.x; i < (int)kMedianScratchWords; i += blockDim.x)
+        __hip_atomic_store(hist + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// hist_dev must be zero on entry (mic_create clears it once; the kernel restores that state).
 hipError_t launch_median(const void *rgba, size_t n_px, uint32_t *hist_dev, uint32_t *out_rgba_dev,
                          hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(hist_dev, 0, kMedianScratchWords * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return e;
-    if (n_px > 0) {
-        size_t blocks = (n_px + 256 * 4 * 8 - 1) / (256 * 4 * 8);
-        if (blocks > 2048) blocks = 2048;
-        if (blocks < 1) blocks = 1;
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(rgba);
-        hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)blocks), dim3(64 * kHistWaves), 0, stream,
-                           p, n_px, hist_dev, 0);
-        // all-pixels fallback: exits at once unless the image had no pixel with alpha > 0
-        hipLaunchKernelGGL(median_hist_kernel, dim3((unsigned)std::min<size_t>(blocks, 512)), dim3(64 * kHistWaves),
-                           0, stream, p, n_px, hist_dev, 1);
-    }
-    hipLaunchKernelGGL(median_select_kernel, dim3(1), dim3(256), 0, stream, hist_dev, out_rgba_dev);
+    const size_t per_block = kTripPx * kHistWaves;  // pixels per block per trip
+    size_t blocks = (n_px + per_block - 1) / per_block;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(median_kernel, dim3((unsigned)blocks), dim3(64 * kHistWaves), 0, stream,
+                       reinterpret_cast<const uint32_t *>(rgba), n_px, hist_dev, out_rgba_dev);
     return hipGetLastError();
 }
 

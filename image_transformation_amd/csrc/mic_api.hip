@@ -176,6 +176,8 @@ extern "C" int mic_create(int device, mic_ctx **out) {
         }
     }
     e = hipMalloc(&ctx->median_scratch, (kMedianScratchWords + 8) * sizeof(uint32_t));
+    // zeroed once: the median kernel's last block leaves it zeroed again after every call
+    if (e == hipSuccess) e = hipMemset(ctx->median_scratch, 0, (kMedianScratchWords + 8) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->median_host), 64, 0);
     if (e != hipSuccess) {
         mic_destroy(ctx);

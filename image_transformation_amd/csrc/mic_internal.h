@@ -106,7 +106,7 @@ hipError_t launch_resample_fused(const RsFused *jobs_dev, int n_jobs, int max_ti
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);
 hipError_t launch_gradient(void *out, int W, int H, const uint8_t c1[3], const uint8_t c2[3], int vertical,
                            hipStream_t stream);
-// hist: uint32 [2][3][256] + counts[2]; zeroed by the launcher.
+// hist: uint32 [2][3][256] + counts[2] + ticket; must be zero on entry, the kernel leaves it zeroed.
 hipError_t launch_median(const void *rgba, size_t n_px, uint32_t *hist_dev, uint32_t *out_rgba_dev,
                          hipStream_t stream);
 constexpr size_t kMedianScratchWords = 2 * 3 * 256 + 8;
