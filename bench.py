@@ -55,6 +55,44 @@ def cpu_baseline(objs, placements, size, budget_s=12.0, max_reps=5000):
                       f"{med * 1e3:.1f} ms, oracle/mic_oracle.c single thread, nproc={os.cpu_count()}"}
 
 
+def cpu_baseline_threads(objs, placements, size, budget_s=8.0):
+    """the same port, one image per core (the C call releases the GIL), different
+    layouts of the batch round-robin.  Reported beside cpu_baseline, not instead of it."""
+    import threading
+
+    import numpy as np
+    import oracle
+    from image_transformation_amd.synthetic import SOLID_BG
+
+    W, H = size
+    try:
+        n_thr = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n_thr = os.cpu_count() or 1
+    n_thr = max(1, min(n_thr, 32))
+    done = [0] * n_thr
+    t_end = time.perf_counter() + budget_s
+
+    def work(i):
+        bg = np.empty((H, W, 4), np.uint8)
+        bg[:] = np.asarray(SOLID_BG, np.uint8)
+        k = i
+        while time.perf_counter() < t_end:
+            oracle.composite(bg, objs, placements[k % len(placements)])
+            done[i] += 1
+            k += n_thr
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(n_thr)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    el = time.perf_counter() - t0
+    return {"value": round(sum(done) * W * H / el / 1e6, 1), "unit": "Mpixels/s", "cores": n_thr, "kind": "port",
+            "sample": f"{sum(done)} whole-canvas composites over {n_thr} threads in {el:.1f} s, one image per thread"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +150,13 @@ def main():
     placements = [flex.layout_to_placements(layouts[v], atlas, size) for v in mine]
     layout_ms = (time.perf_counter() - t0) * 1e3 / max(len(mine), 1)
     rows = [coerce_placements(atlas, pl) for pl in placements]
+    # the same maths through the C++ placer (mic_flex_place) on the JSON text, as render() does it
+    texts = [json.dumps(layouts[v]) for v in mine]
+    t0 = time.perf_counter()
+    native_rows = [flex.native_boxes(t, atlas, size) for t in texts]
+    native_ms = (time.perf_counter() - t0) * 1e3 / max(len(mine), 1)
+    assert all(nr is None or [tuple(r) for r in nr] == [tuple(r) for r in row] for nr, row in zip(native_rows, rows))
+    box_px = sum(max(1, r[3] - r[1]) * max(1, r[4] - r[2]) for row in rows for r in row)
     plan = CompositeBatch(atlas, [SolidCanvas(size, synthetic.SOLID_BG)] * len(mine), rows)
 
     # rotating output sets, > 256 MiB in total
@@ -180,7 +225,9 @@ def main():
                      "read_frac_of_peak": round(4 * stats["layer_pixels"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
                      if kernel_ms > 0 else None},
         "atlas": {"bytes": atlas.nbytes, "upload_or_broadcast_ms": round(atlas_ms, 3)},
-        "host_layout_ms_per_image": round(layout_ms, 3),
+        "host_layout_ms_per_image": {"python_mirror": round(layout_ms, 3),
+                                     "native_mic_flex_place": round(native_ms, 4) if all(r is not None for r in native_rows) else None},
+        "box_area_Mpixels_per_s": round(box_px * world * args.steps / elapsed / 1e6, 1),
     }
 
     if rank == 0 and world == 1 and not args.no_extras:
@@ -221,8 +268,43 @@ def main():
                                              "resample_ms": round(r2 / n2, 3), "composite_ms": round(c2 / n2, 4),
                                              "Mpixels_per_s": round(W * H * 10 / e2 / 1e6, 1)}
 
+        # PCIe-inclusive step: job-table upload + composite + D2H of every canvas into pinned memory
+        # (SURVEY 8d's end-to-end figure; never `value`)
+        host = [torch.empty((H, W, 4), dtype=torch.uint8, pin_memory=True) for _ in range(len(rows))]
+        for _ in range(2):
+            for h, o in zip(host, plan.run(out_sets[0])):
+                h.copy_(o, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(5):
+            for h, o in zip(host, plan.run(out_sets[k % n_sets])):
+                h.copy_(o, non_blocking=True)
+        torch.cuda.synchronize()
+        e3 = (time.perf_counter() - t0) / 5
+        result["pcie_inclusive"] = {"ms_per_step": round(e3 * 1e3, 3), "Mpixels_per_s": round(B * W * H / e3 / 1e6, 1),
+                                    "d2h_GBps": round(B * W * H * 4 / e3 / 1e9, 1)}
+        del host
+        # background synthesis on the same canvas size: median colour of a 4K RGBA image + solid fill
+        import ctypes
+        P = ctypes.c_void_p
+        lib = _native.lib()
+        img = torch.randint(0, 256, (H, W, 4), dtype=torch.uint8, device=dev)
+        res = torch.empty(4, dtype=torch.uint8, device=dev)
+        sp = P(ctx.stream_ptr())
+        for name, fn in (("median_4k_noise_us", lambda: lib.mic_median_rgb_dev(ctx.handle, P(img.data_ptr()), W, H, P(res.data_ptr()), sp)),):
+            for _ in range(3):
+                _native.check(fn())
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            result[name] = round(e0.elapsed_time(e1) / 50 * 1e3, 1)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(objs, placements[0], size)
+        result["cpu_baseline_all_cores"] = cpu_baseline_threads(objs, placements, size)
     elif rank == 0:
         result["cpu_baseline"] = None
 
