@@ -117,114 +117,274 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const RsJob *__restrict
     reinterpret_cast<gptr>(J.dst)[(size_t)yy * J.out_w + x] = o;
 }
 
-// Fused resize: one workgroup produces a tx x ty tile of the FINAL image.
-//   1. the tile's slices of both coefficient tables go to LDS (horizontal taps transposed to
-//      [k][x] so that lanes = adjacent columns read adjacent words);
-//   2. the source window the tile depends on (its rows' vertical taps x its columns' horizontal
-//      taps) is read from HBM once, premultiplied once per pixel, and kept in LDS;
-//   3. horizontal pass LDS -> LDS: the 8-bit intermediate Pillow keeps between its two passes
-//      (ImagingResampleHorizontal_8bpc output) for exactly the window rows;
-//   4. vertical pass LDS -> registers, unpremultiply, one coalesced store per output row segment.
-// Arithmetic is identical to the two-pass kernels above (and to Pillow): bit-exact.  The host picks
-// tx/ty per layer so that the window fits LDS (mic_api.hip: choose_fused); layers shrunk so hard
-// that even a 16x1 tile's window does not fit fall back to the two-pass kernels through HBM.
-__global__ __launch_bounds__(256) void resample_fused_kernel(const RsFused *__restrict__ jobs) {
-    extern __shared__ uint32_t lds[];
-    const RsFused J = jobs[blockIdx.y];
+// Fused resize on the matrix cores: one workgroup produces a (16 tx16) x (16 ty16) tile of the FINAL
+// image.
+//
+// A separable resample is a banded matrix product per axis -- out = in x K^T with K[x][k] the taps
+// of output sample x -- and it is exact integer arithmetic, so it maps onto v_mfma_i32_16x16x64_i8
+// without touching the result: the 8-bit samples are stored as signed bytes (s - 128, the constant
+// 128 * sum(taps) goes into the accumulator's initial value together with Pillow's 2^21 rounding
+// term) and each 22-bit tap is split into three signed-byte digits, c = d0 + 256 d1 + 65536 d2,
+// one MFMA per digit; acc0 + (acc1 << 8) + (acc2 << 16) is then exactly Pillow's int32 sum.  A
+// 16x16x64 MFMA covers 16 output samples and a 64-sample window -- wider than the band for any
+// scale down to ~1/3 -- so the zeros outside the band are free.  (The VALU version of this kernel
+// spent ~12 instructions per tap per pixel and was bound by integer issue: 0.20 ms for the 32
+// layers of the C3 placements workload.)
+//
+//   1. source window rows x columns -> LDS, premultiplied once per pixel, split into four channel
+//      planes [row][column] of signed bytes;
+//   2. horizontal pass: A = 16 window rows x 64 columns of one plane (ds_read_b128 per lane),
+//      B = the x-tile's tap digits (host-built fragments, resample_coeffs.cpp), D = 16 rows x 16
+//      outputs; clip8 -> the 8-bit intermediate Pillow keeps between its passes, written
+//      transposed into planes [x][row] so that the next pass again reads 16 consecutive bytes;
+//   3. vertical pass: A = the y-tile's tap digits, B = 64 intermediate rows x 16 columns,
+//      D = 16 output rows x 16 columns; clip8, interleave the planes, unpremultiply, store.
+// The k index of both operands is defined by the same (lane >> 4, byte) -> window position map, so
+// the result does not depend on the hardware's internal k order; C/D follow the documented
+// col = lane & 15, row = 4 (lane >> 4) + reg map.  Bit-exact with the two-pass kernels above.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) v4i *gv4ptr;
+
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte value {hi (bytes 4..7), lo (bytes 0..3)}.
+__device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+    return __builtin_amdgcn_perm(hi, lo, sel);
+}
+
+// Convert.c rgbA2rgba on two channels at once: x holds two bytes in 16-bit lanes (0x00XX00YY), the
+// result the two products div255(c * a + 128) in the same lanes.  No lane can carry into the other:
+// c * a + 128 <= 65153 and adding (t >> 8) <= 254 stays below 65536.
+__device__ __forceinline__ uint32_t premultiply2(uint32_t x, uint32_t a) {
+    const uint32_t t = __umul24(x, a) + 0x00800080u;
+    return ((((t >> 8) & 0x00FF00FFu) + t) >> 8) & 0x00FF00FFu;
+}
+
+// clip8 of four 32-bit sums -> four bytes of one word, byte i from v[i].  v_ashr_pk_u8_i32 shifts,
+// saturates to 0..255 and packs two values per instruction; it writes only D[15:0] (which is what
+// hipcc's own use of it gets wrong, see clip8), so the halves are masked/shifted explicitly.
+__device__ __forceinline__ uint32_t clip8x4(int v0, int v1, int v2, int v3) {
+    uint32_t lo, hi;
+    asm volatile("v_ashr_pk_u8_i32 %0, %1, %2, 22" : "=v"(lo) : "v"(v0), "v"(v1));
+    asm volatile("v_ashr_pk_u8_i32 %0, %1, %2, 22" : "=v"(hi) : "v"(v2), "v"(v3));
+    return (lo & 0xFFFFu) | (hi << 16);
+}
+
+__device__ __forceinline__ int combine(int a0, int a1, int a2) {
+    return (int)((uint32_t)a0 + ((uint32_t)a1 << 8) + ((uint32_t)a2 << 16));
+}
+
+__global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__restrict__ jobs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
+    const RsMfma J = jobs[blockIdx.y];
     const int tile = blockIdx.x;
     if (tile >= J.tiles_x * J.tiles_y) return;
     const int tyi = tile / J.tiles_x, txi = tile - tyi * J.tiles_x;
-    const int ox0 = txi * J.tx, oy0 = tyi * J.ty;
-    const int tw = min(J.tx, J.dw - ox0), th = min(J.ty, J.dh - oy0);
-    const bool need_h = J.kx > 0, need_v = J.ky > 0;
-    const int tid = threadIdx.x, lane = tid & 63, wy = tid >> 6;
+    const int xt0 = txi * J.tx16, yt0 = tyi * J.ty16;
+    const int n_xt = min(J.tx16, ((J.dw + 15) >> 4) - xt0), n_yt = min(J.ty16, ((J.dh + 15) >> 4) - yt0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lh = lane >> 4;
 
-    uint32_t *srcT = lds;                                       // [max_r][max_c]
-    uint32_t *mid = srcT + (size_t)J.max_r * J.max_c;           // [max_r][tx]
-    int32_t *cH = reinterpret_cast<int32_t *>(mid + (size_t)J.max_r * J.tx);  // [kx][tx]
-    int32_t *cV = cH + J.kx * J.tx;                             // [ty][ky]
-    int32_t *bH = cV + J.ty * J.ky;                             // [tx][2]
-    int32_t *bV = bH + 2 * J.tx;                                // [ty][2]
+    gv4ptr hmeta = reinterpret_cast<gv4ptr>(J.hmeta), vmeta = reinterpret_cast<gv4ptr>(J.vmeta);
+    const int c_lo = hmeta[xt0][0], c_hi = min(J.sw, hmeta[xt0 + n_xt - 1][3]);
+    const int r_lo = vmeta[yt0][0], r_hi = min(J.sh, vmeta[yt0 + n_yt - 1][3]);
+    const int R = r_hi - r_lo;
+    // columns are loaded in groups of 4: round the window up to that, inside the image
+    const int C = min((c_hi - c_lo + 3) & ~3, J.sw - c_lo);
+    const int plane_s = J.rows16 * J.pitch_c;       // bytes per source plane
+    const int plane_m = 16 * J.tx16 * J.pitch_r;    // bytes per intermediate plane
+    uint8_t *srcP = lds8;                           // [4][rows16][pitch_c]
+    uint8_t *midT = lds8 + 4 * plane_s;             // [4][16 tx16][pitch_r]
 
-    if (need_h) {
-        gciptr hb = reinterpret_cast<gciptr>(J.hbounds) + 2 * ox0;
-        gciptr hc = reinterpret_cast<gciptr>(J.hcoeffs) + (size_t)ox0 * J.kx;
-        for (int i = tid; i < 2 * tw; i += 256) bH[i] = hb[i];
-        for (int i = tid; i < tw * J.kx; i += 256) {
-            const int x = i / J.kx, k = i - x * J.kx;
-            cH[k * J.tx + x] = hc[i];
+    // ---- 1. source window -> premultiplied signed-byte planes.  Items = (row, group of 4 columns),
+    // dealt round-robin to the 256 threads; four 16-byte loads are in flight per thread.  The load
+    // itself is unconditional (index clamped into the image); only a group cut by the image's right
+    // edge is re-read pixel by pixel.
+    {
+        gcptr src = reinterpret_cast<gcptr>(J.src);
+        const int G = (C + 3) >> 2;
+        const int dq = 256 / G, dr = 256 - dq * G;
+        const int last4 = J.sw * J.sh - 4;  // the host keeps images smaller than 4 px off this kernel
+        int rr = tid / G, g = tid - rr * G;
+        while (rr < R) {
+            int irr[4], ig[4];
+            u32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                irr[k] = rr;
+                ig[k] = g;
+                const int idx = (r_lo + min(rr, R - 1)) * J.sw + c_lo + 4 * g;
+                __builtin_memcpy(&v[k], (const void *)(src + min(idx, last4)), 16);
+                rr += dq;
+                g += dr;
+                if (g >= G) { g -= G; ++rr; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (irr[k] >= R) break;
+                const int cc = 4 * ig[k];
+                uint32_t p0 = v[k][0], p1 = v[k][1], p2 = v[k][2], p3 = v[k][3];
+                if (cc + 4 > C) {  // cut by the image's right edge (rare)
+                    gcptr row = src + (size_t)(r_lo + irr[k]) * J.sw + c_lo + cc;
+                    p0 = row[0];
+                    p1 = cc + 1 < C ? row[1] : 0u;
+                    p2 = cc + 2 < C ? row[2] : 0u;
+                    p3 = 0u;
+                }
+                const uint32_t px[4] = {p0, p1, p2, p3};
+                uint32_t rb[4], ga[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = px[j] >> 24;
+                    rb[j] = premultiply2(px[j] & 0x00FF00FFu, a);
+                    ga[j] = premultiply2(((px[j] >> 8) & 0xFFu) | 0x00FF0000u, a);  // div255(255 a + 128) == a
+                }
+                // 4 px x 2 lanes -> one word per plane: {c0, c1, c2, c3} of the four pixels
+                const uint32_t rb01 = byte_perm(rb[1], rb[0], 0x06020400u), rb23 = byte_perm(rb[3], rb[2], 0x06020400u);
+                const uint32_t ga01 = byte_perm(ga[1], ga[0], 0x06020400u), ga23 = byte_perm(ga[3], ga[2], 0x06020400u);
+                uint32_t *dst = reinterpret_cast<uint32_t *>(srcP + irr[k] * J.pitch_c + cc);
+                dst[0 * (plane_s >> 2)] = byte_perm(rb23, rb01, 0x05040100u) ^ 0x80808080u;  // R
+                dst[1 * (plane_s >> 2)] = byte_perm(ga23, ga01, 0x05040100u) ^ 0x80808080u;  // G
+                dst[2 * (plane_s >> 2)] = byte_perm(rb23, rb01, 0x07060302u) ^ 0x80808080u;  // B
+                dst[3 * (plane_s >> 2)] = byte_perm(ga23, ga01, 0x07060302u) ^ 0x80808080u;  // A
+            }
         }
     }
-    if (need_v) {
-        gciptr vb = reinterpret_cast<gciptr>(J.vbounds) + 2 * oy0;
-        gciptr vc = reinterpret_cast<gciptr>(J.vcoeffs) + (size_t)oy0 * J.ky;
-        for (int i = tid; i < 2 * th; i += 256) bV[i] = vb[i];
-        for (int i = tid; i < th * J.ky; i += 256) cV[i] = vc[i];
-    }
     __syncthreads();
 
-    // source window [r0, r1) x [c0, c1)
-    const int c0 = need_h ? bH[0] : ox0;
-    const int c1 = need_h ? bH[2 * (tw - 1)] + bH[2 * (tw - 1) + 1] : ox0 + tw;
-    const int r0 = need_v ? bV[0] : oy0;
-    const int r1 = need_v ? bV[2 * (th - 1)] + bV[2 * (th - 1) + 1] : oy0 + th;
-    const int C = c1 - c0, R = r1 - r0;
-    gcptr src = reinterpret_cast<gcptr>(J.src);
-    for (int rr = wy; rr < R; rr += 4) {
-        gcptr row = src + (size_t)(r0 + rr) * J.sw + c0;
-        for (int cc = lane; cc < C; cc += 64) srcT[rr * J.max_c + cc] = premultiply(row[cc]);
-    }
-    __syncthreads();
-
-    // horizontal pass: window rows -> 8-bit intermediate
-    for (int rr = wy; rr < R; rr += 4) {
-        const uint32_t *srow = srcT + rr * J.max_c;
-        for (int xx = lane; xx < tw; xx += 64) {
-            uint32_t o;
-            if (need_h) {
-                const int first = bH[2 * xx] - c0, n = bH[2 * xx + 1];
-                int32_t s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0, s3 = s0;
-                for (int k = 0; k < n; ++k) {
-                    const uint32_t p = srow[first + k];
-                    const int32_t c = cH[k * J.tx + xx];
-                    mac4(s0, s1, s2, s3, p, c);
-                }
-                o = pack_clip(s0, s1, s2, s3);
-            } else {
-                o = srow[xx];
+    // ---- 2. horizontal pass: window rows -> 8-bit intermediate, transposed
+    {
+        gciptr hbias = reinterpret_cast<gciptr>(J.hbias);
+        gv4ptr hfrag = reinterpret_cast<gv4ptr>(J.hfrag);
+        const int n_rt = (R + 15) >> 4;
+        int cur = -1, bias = 0;
+        v4i m = {0, 0, 0, 0}, b0 = m, b1 = m, b2 = m;
+        for (int pair = wave; pair < n_xt * n_rt; pair += 4) {
+            const int xi = pair / n_rt, rt = pair - xi * n_rt;
+            if (xi != cur) {  // wave-uniform: a wave's consecutive pairs mostly share the x-tile
+                cur = xi;
+                m = hmeta[xt0 + xi];
+                bias = hbias[(xt0 + xi) * 16 + l15];
+                gv4ptr f = hfrag + (size_t)m[2] * 3 * 64 + lane;
+                b0 = f[0]; b1 = f[64]; b2 = f[128];
             }
-            mid[rr * J.tx + xx] = o;
+            const int off = m[0] - c_lo;  // multiple of 16
+            v4i acc[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[c][0] = v4i{bias, bias, bias, bias};
+                acc[c][1] = v4i{0, 0, 0, 0};
+                acc[c][2] = v4i{0, 0, 0, 0};
+            }
+            const uint8_t *arow = srcP + (rt * 16 + l15) * J.pitch_c + off + 16 * lh;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const v4i a = *reinterpret_cast<const v4i *>(arow + c * plane_s);
+                acc[c][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b0, acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1, acc[c][1], 0, 0, 0);
+                acc[c][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b2, acc[c][2], 0, 0, 0);
+            }
+            for (int ch = 1; ch < m[1]; ++ch) {  // windows wider than 64 samples (shrinks below ~1/3)
+                gv4ptr f = hfrag + (size_t)(m[2] + ch) * 3 * 64 + lane;
+                const v4i e0 = f[0], e1 = f[64], e2 = f[128];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const v4i a = *reinterpret_cast<const v4i *>(arow + 64 * ch + c * plane_s);
+                    acc[c][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, e0, acc[c][0], 0, 0, 0);
+                    acc[c][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, e1, acc[c][1], 0, 0, 0);
+                    acc[c][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, e2, acc[c][2], 0, 0, 0);
+                }
+            }
+            // D[row = 4 lh + reg (window row)][col = l15 (x)]: 4 consecutive rows of one column
+            uint8_t *mrow = midT + (xi * 16 + l15) * J.pitch_r + rt * 16 + 4 * lh;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t w = clip8x4(combine(acc[c][0][0], acc[c][1][0], acc[c][2][0]),
+                                           combine(acc[c][0][1], acc[c][1][1], acc[c][2][1]),
+                                           combine(acc[c][0][2], acc[c][1][2], acc[c][2][2]),
+                                           combine(acc[c][0][3], acc[c][1][3], acc[c][2][3]));
+                *reinterpret_cast<uint32_t *>(mrow + c * plane_m) = w ^ 0x80808080u;
+            }
         }
     }
     __syncthreads();
 
-    // vertical pass + unpremultiply + store
-    gptr dst = reinterpret_cast<gptr>(J.dst);
-    for (int yy = wy; yy < th; yy += 4) {
-        for (int xx = lane; xx < tw; xx += 64) {
-            uint32_t o;
-            if (need_v) {
-                const int first = bV[2 * yy] - r0, n = bV[2 * yy + 1];
-                const int32_t *kv = cV + yy * J.ky;
-                int32_t s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0, s3 = s0;
-                for (int k = 0; k < n; ++k) {
-                    const uint32_t p = mid[(first + k) * J.tx + xx];
-                    const int32_t c = kv[k];
-                    mac4(s0, s1, s2, s3, p, c);
-                }
-                o = pack_clip(s0, s1, s2, s3);
-            } else {
-                o = mid[yy * J.tx + xx];
+    // ---- 3. vertical pass + unpremultiply + store
+    {
+        gciptr vbias = reinterpret_cast<gciptr>(J.vbias);
+        gv4ptr vfrag = reinterpret_cast<gv4ptr>(J.vfrag);
+        gptr dst = reinterpret_cast<gptr>(J.dst);
+        int cur = -1;
+        v4i m = {0, 0, 0, 0}, a0 = m, a1 = m, a2 = m, bias = m;
+        for (int pair = wave; pair < n_yt * n_xt; pair += 4) {
+            const int yi = pair / n_xt, xi = pair - yi * n_xt;
+            if (yi != cur) {
+                cur = yi;
+                m = vmeta[yt0 + yi];
+                bias = *reinterpret_cast<gv4ptr>(vbias + (yt0 + yi) * 16 + 4 * lh);
+                gv4ptr f = vfrag + (size_t)m[2] * 3 * 64 + lane;
+                a0 = f[0]; a1 = f[64]; a2 = f[128];
             }
-            dst[(size_t)(oy0 + yy) * J.dw + ox0 + xx] = unpremultiply(o);
+            const int off = m[0] - r_lo;  // multiple of 16
+            v4i acc[4][3];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[c][0] = bias;
+                acc[c][1] = v4i{0, 0, 0, 0};
+                acc[c][2] = v4i{0, 0, 0, 0};
+            }
+            const uint8_t *bcol = midT + (xi * 16 + l15) * J.pitch_r + off + 16 * lh;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const v4i b = *reinterpret_cast<const v4i *>(bcol + c * plane_m);
+                acc[c][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b, acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b, acc[c][1], 0, 0, 0);
+                acc[c][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b, acc[c][2], 0, 0, 0);
+            }
+            for (int ch = 1; ch < m[1]; ++ch) {
+                gv4ptr f = vfrag + (size_t)(m[2] + ch) * 3 * 64 + lane;
+                const v4i e0 = f[0], e1 = f[64], e2 = f[128];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const v4i b = *reinterpret_cast<const v4i *>(bcol + 64 * ch + c * plane_m);
+                    acc[c][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(e0, b, acc[c][0], 0, 0, 0);
+                    acc[c][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(e1, b, acc[c][1], 0, 0, 0);
+                    acc[c][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(e2, b, acc[c][2], 0, 0, 0);
+                }
+            }
+            // D[row = 4 lh + reg (output row)][col = l15 (x)]: per channel the bytes of 4 rows
+            uint32_t w[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                w[c] = clip8x4(combine(acc[c][0][0], acc[c][1][0], acc[c][2][0]),
+                               combine(acc[c][0][1], acc[c][1][1], acc[c][2][1]),
+                               combine(acc[c][0][2], acc[c][1][2], acc[c][2][2]),
+                               combine(acc[c][0][3], acc[c][1][3], acc[c][2][3]));
+            // 4 channels x 4 rows -> 4 RGBA pixels (byte transpose)
+            const uint32_t rg01 = byte_perm(w[1], w[0], 0x05010400u), rg23 = byte_perm(w[1], w[0], 0x07030602u);
+            const uint32_t ba01 = byte_perm(w[3], w[2], 0x05010400u), ba23 = byte_perm(w[3], w[2], 0x07030602u);
+            const uint32_t px[4] = {byte_perm(ba01, rg01, 0x05040100u), byte_perm(ba01, rg01, 0x07060302u),
+                                    byte_perm(ba23, rg23, 0x05040100u), byte_perm(ba23, rg23, 0x07060302u)};
+            const int ox = (xt0 + xi) * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oy = (yt0 + yi) * 16 + 4 * lh + r;
+                if (ox < J.dw && oy < J.dh) dst[(size_t)oy * J.dw + ox] = unpremultiply(px[r]);
+            }
         }
     }
 }
 
-hipError_t launch_resample_fused(const RsFused *jobs_dev, int n_jobs, int max_tiles, size_t lds_bytes,
-                                 hipStream_t stream) {
+hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int max_tiles, size_t lds_bytes,
+                                hipStream_t stream) {
     if (n_jobs <= 0 || max_tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(resample_fused_kernel, dim3((unsigned)max_tiles, (unsigned)n_jobs), dim3(256), lds_bytes, stream,
+    static size_t attr_set = 0;  // largest dynamic-LDS size the kernel has been opted in for
+    if (lds_bytes > attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_mfma_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsMfmaMaxLds);
+        if (e != hipSuccess) return e;
+        attr_set = kRsMfmaMaxLds;
+    }
+    hipLaunchKernelGGL(resample_mfma_kernel, dim3((unsigned)max_tiles, (unsigned)n_jobs), dim3(256), lds_bytes, stream,
                        jobs_dev);
     return hipGetLastError();
 }

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <new>
 #include <tuple>
 #include <unordered_map>
@@ -111,7 +112,13 @@ struct CoefEntry {
     int ksize = 0;
     int32_t *bounds = nullptr;  // device
     int32_t *coeffs = nullptr;  // device
-    std::vector<int32_t> bounds_host;  // [out][2], for sizing the fused kernel's LDS windows
+};
+// One axis in the MFMA kernel's fragment form (resample_coeffs.h AxisFrags), one device allocation.
+struct FragEntry {
+    int tiles = 0;
+    void *dev = nullptr;  // meta | bias | frags
+    uint64_t meta = 0, bias = 0, frags = 0;
+    std::shared_ptr<std::vector<int32_t>> meta_host;  // [tiles][4], for sizing the LDS windows
 };
 }  // namespace
 
@@ -122,6 +129,7 @@ struct mic_ctx {
     void *arena = nullptr;
     size_t arena_cap = 0;
     std::map<CoefKey, CoefEntry> coefs;
+    std::map<CoefKey, FragEntry> frags;  // key.transposed unused (0)
     uint32_t *median_scratch = nullptr;  // device: histogram words + 1 result word
     uint32_t *median_host = nullptr;     // pinned
     hipStream_t last_stream = nullptr;
@@ -200,6 +208,8 @@ extern "C" int mic_destroy(mic_ctx *ctx) {
         if (kv.second.bounds) (void)hipFree(kv.second.bounds);
         if (kv.second.coeffs) (void)hipFree(kv.second.coeffs);
     }
+    for (auto &kv : ctx->frags)
+        if (kv.second.dev) (void)hipFree(kv.second.dev);
     for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->median_scratch) (void)hipFree(ctx->median_scratch);
@@ -269,7 +279,6 @@ static int get_coefs(mic_ctx *ctx, int in, int out, int filter, bool transposed,
     AxisTable t = build_axis_table(in, out, filter);
     CoefEntry e;
     e.ksize = t.ksize;
-    e.bounds_host = t.bounds;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e.bounds), t.bounds.size() * sizeof(int32_t)));
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&e.coeffs), t.coeffs.size() * sizeof(int32_t)));
     // Pageable source: the runtime stages it before returning, the vectors may die afterwards.
@@ -281,6 +290,33 @@ static int get_coefs(mic_ctx *ctx, int in, int out, int filter, bool transposed,
         HIP_TRY(hipMemcpy(e.coeffs, t.coeffs.data(), t.coeffs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     ctx->coefs[key] = e;
+    *res = e;
+    return MIC_OK;
+}
+
+// in == out: the identity table (Pillow skips that pass; one tap of weight 1.0 gives the same bytes).
+static int get_frags(mic_ctx *ctx, int in, int out, int filter, FragEntry *res) {
+    const CoefKey key{in, out, in == out ? -1 : filter, 0};
+    auto it = ctx->frags.find(key);
+    if (it != ctx->frags.end()) {
+        *res = it->second;
+        return MIC_OK;
+    }
+    const AxisFrags f = build_axis_frags(in == out ? identity_axis_table(in) : build_axis_table(in, out, filter));
+    FragEntry e;
+    e.tiles = f.tiles;
+    const size_t meta_b = align_up(f.meta.size() * sizeof(int32_t), 64);
+    const size_t bias_b = align_up(f.bias.size() * sizeof(int32_t), 64);
+    HIP_TRY(hipMalloc(&e.dev, meta_b + bias_b + f.frags.size()));
+    e.meta = reinterpret_cast<uint64_t>(e.dev);
+    e.bias = e.meta + meta_b;
+    e.frags = e.bias + bias_b;
+    // Pageable sources: the runtime stages them before returning.
+    HIP_TRY(hipMemcpy(reinterpret_cast<void *>(e.meta), f.meta.data(), f.meta.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(reinterpret_cast<void *>(e.bias), f.bias.data(), f.bias.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(reinterpret_cast<void *>(e.frags), f.frags.data(), f.frags.size(), hipMemcpyHostToDevice));
+    e.meta_host = std::make_shared<std::vector<int32_t>>(f.meta);
+    ctx->frags[key] = e;
     *res = e;
     return MIC_OK;
 }
@@ -429,48 +465,64 @@ struct ResizePlan {
     size_t tmp_off = 0;   // scratch offset of the horizontal pass output (two-pass fallback, both axes)
     size_t dst_off = 0;   // scratch offset of the final image (unused when dst_ptr is set)
     uint64_t dst_ptr = 0; // caller-provided destination (mic_resize)
-    // fused kernel (source window + 8-bit intermediate in LDS); tx == 0: two-pass fallback
-    int tx = 0, ty = 0, max_c = 0, max_r = 0;
+    // MFMA kernel (source planes + 8-bit intermediate in LDS); tx16 == 0: two-pass fallback
+    int tx16 = 0, ty16 = 0, pitch_c = 0, pitch_r = 0, rows16 = 0;
 };
 
 struct PassTables {
-    std::vector<RsFused> fused;
+    std::vector<RsMfma> fused;
     int fused_max_tiles = 0;
     size_t fused_lds = 0;
     std::vector<RsJob> h, v;
     int max_h_out_w = 0, max_h_rows = 0, max_v_out_w = 0, max_v_out_h = 0;
 };
 
-// Largest source extent (first tap of the tile's first sample .. last tap of its last sample) over
-// all tiles of `tile` output samples along one axis.
-int max_window(const std::vector<int32_t> &bounds, int out, int tile) {
-    int best = 0;
-    for (int o0 = 0; o0 < out; o0 += tile) {
-        const int o1 = std::min(out, o0 + tile) - 1;
-        best = std::max(best, bounds[2 * o1] + bounds[2 * o1 + 1] - bounds[2 * o0]);
+// Over all workgroup tiles of `per` 16-sample tiles along one axis: the largest window extent the
+// kernel may touch (first tile's window start .. end of the last 64-sample chunk of any of its
+// tiles) and the largest span of samples it actually needs (.. one past the last tap).
+void window_extents(const std::vector<int32_t> &meta, int tiles, int per, int *touched, int *needed) {
+    *touched = 0;
+    *needed = 0;
+    for (int t0 = 0; t0 < tiles; t0 += per) {
+        const int t1 = std::min(tiles, t0 + per);
+        const int lo = meta[4 * t0];
+        int end = lo;
+        for (int t = t0; t < t1; ++t) end = std::max(end, meta[4 * t] + 64 * meta[4 * t + 1]);
+        *touched = std::max(*touched, end - lo);
+        *needed = std::max(*needed, meta[4 * (t1 - 1) + 3] - lo);
     }
-    return best;
 }
 
-// Pick the output tile of the fused kernel for one layer: the biggest of a short list whose source
-// window + intermediate + coefficient slices fit LDS.  Leaves tx == 0 when nothing fits.
+// LDS rows are read 16 bytes per lane by lanes that differ in the row: an odd number of 16-byte
+// units per row spreads them over the banks.
+int odd_pitch(int bytes) {
+    int p = (bytes + 15) / 16;
+    if ((p & 1) == 0) ++p;
+    return 16 * p;
+}
+
+// Pick the workgroup tile of the MFMA kernel for one layer: the biggest of a short list whose
+// source planes + intermediate planes fit LDS, preferring sizes that let two workgroups share a CU.
+// Leaves tx16 == 0 when nothing fits (extreme shrinks: the two-pass kernels take those).
 int choose_fused(mic_ctx *ctx, ResizePlan *p, int filter) {
-    const bool need_h = p->dw != p->sw, need_v = p->dh != p->sh;
-    CoefEntry ch, cv;
-    if (need_h) if (int rc = get_coefs(ctx, p->sw, p->dw, filter, false, &ch)) return rc;
-    if (need_v) if (int rc = get_coefs(ctx, p->sh, p->dh, filter, false, &cv)) return rc;
-    const int kx = need_h ? ch.ksize : 0, ky = need_v ? cv.ksize : 0;
-    static const int kTiles[][2] = {{64, 16}, {64, 8}, {64, 4}, {32, 4}, {32, 2}, {16, 2}, {16, 1}};
-    for (const auto &t : kTiles) {
-        const int tx = t[0], ty = t[1];
-        const int mc = need_h ? max_window(ch.bounds_host, p->dw, tx) : tx;
-        const int mr = need_v ? max_window(cv.bounds_host, p->dh, ty) : ty;
-        if (rs_fused_lds_bytes(mc, mr, tx, ty, kx, ky) <= kRsFusedMaxLds) {
-            p->tx = tx; p->ty = ty; p->max_c = mc; p->max_r = mr;
-            return MIC_OK;
+    FragEntry fh, fv;
+    if (int rc = get_frags(ctx, p->sw, p->dw, filter, &fh)) return rc;
+    if (int rc = get_frags(ctx, p->sh, p->dh, filter, &fv)) return rc;
+    static const int kTiles[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
+    p->tx16 = 0;
+    if ((int64_t)p->sw * p->sh < 4) return MIC_OK;  // the kernel's 16-byte loads need 4 pixels to clamp into
+    for (const size_t cap : {kRsMfmaPreferredLds, kRsMfmaMaxLds}) {
+        for (const auto &t : kTiles) {
+            int tc, nc, tr, nr;
+            window_extents(*fh.meta_host, fh.tiles, t[0], &tc, &nc);
+            window_extents(*fv.meta_host, fv.tiles, t[1], &tr, &nr);
+            const int pitch_c = odd_pitch(tc), pitch_r = odd_pitch(tr), rows16 = (std::min(nr, p->sh) + 15) / 16 * 16;
+            if (rs_mfma_lds_bytes(rows16, pitch_c, t[0], pitch_r) <= cap) {
+                p->tx16 = t[0]; p->ty16 = t[1]; p->pitch_c = pitch_c; p->pitch_r = pitch_r; p->rows16 = rows16;
+                return MIC_OK;
+            }
         }
     }
-    p->tx = 0;
     return MIC_OK;
 }
 
@@ -479,22 +531,21 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
     for (const ResizePlan &p : plans) {
         const bool need_h = p.dw != p.sw, need_v = p.dh != p.sh;
         const uint64_t dst = p.dst_ptr ? p.dst_ptr : arena + p.dst_off;
-        if (p.tx > 0) {
-            CoefEntry ch, cv;
-            if (need_h) if (int rc = get_coefs(ctx, p.sw, p.dw, filter, false, &ch)) return rc;
-            if (need_v) if (int rc = get_coefs(ctx, p.sh, p.dh, filter, false, &cv)) return rc;
-            RsFused f{};
+        if (p.tx16 > 0) {
+            FragEntry fh, fv;
+            if (int rc = get_frags(ctx, p.sw, p.dw, filter, &fh)) return rc;
+            if (int rc = get_frags(ctx, p.sh, p.dh, filter, &fv)) return rc;
+            RsMfma f{};
             f.src = p.src; f.dst = dst;
-            f.hbounds = reinterpret_cast<uint64_t>(ch.bounds); f.hcoeffs = reinterpret_cast<uint64_t>(ch.coeffs);
-            f.vbounds = reinterpret_cast<uint64_t>(cv.bounds); f.vcoeffs = reinterpret_cast<uint64_t>(cv.coeffs);
+            f.hmeta = fh.meta; f.hbias = fh.bias; f.hfrag = fh.frags;
+            f.vmeta = fv.meta; f.vbias = fv.bias; f.vfrag = fv.frags;
             f.sw = p.sw; f.sh = p.sh; f.dw = p.dw; f.dh = p.dh;
-            f.kx = need_h ? ch.ksize : 0; f.ky = need_v ? cv.ksize : 0;
-            f.tx = p.tx; f.ty = p.ty;
-            f.tiles_x = (p.dw + p.tx - 1) / p.tx; f.tiles_y = (p.dh + p.ty - 1) / p.ty;
-            f.max_c = p.max_c; f.max_r = p.max_r;
+            f.tx16 = p.tx16; f.ty16 = p.ty16;
+            f.tiles_x = (fh.tiles + p.tx16 - 1) / p.tx16; f.tiles_y = (fv.tiles + p.ty16 - 1) / p.ty16;
+            f.pitch_c = p.pitch_c; f.pitch_r = p.pitch_r; f.rows16 = p.rows16;
             pt->fused.push_back(f);
             pt->fused_max_tiles = std::max(pt->fused_max_tiles, f.tiles_x * f.tiles_y);
-            pt->fused_lds = std::max(pt->fused_lds, rs_fused_lds_bytes(f.max_c, f.max_r, f.tx, f.ty, f.kx, f.ky));
+            pt->fused_lds = std::max(pt->fused_lds, rs_mfma_lds_bytes(f.rows16, f.pitch_c, f.tx16, f.pitch_r));
             continue;
         }
         uint64_t v_src = p.src;
@@ -561,7 +612,7 @@ struct mic_plan {
 static void plan_offsets(mic_plan *P) {
     P->off_layers = align_up(sizeof(Job) * P->jobs.size(), 64);
     P->off_f = align_up(P->off_layers + sizeof(Layer) * P->layers.size(), 64);
-    P->off_h = align_up(P->off_f + sizeof(RsFused) * P->pt.fused.size(), 64);
+    P->off_h = align_up(P->off_f + sizeof(RsMfma) * P->pt.fused.size(), 64);
     P->off_v = align_up(P->off_h + sizeof(RsJob) * P->pt.h.size(), 64);
     P->total = align_up(P->off_v + sizeof(RsJob) * P->pt.v.size(), 64);
 }
@@ -645,7 +696,7 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                     rp.src = reinterpret_cast<uint64_t>(A->blob) + E.offset;
                     rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
                     if (int rc = choose_fused(ctx, &rp, filter)) return rc;
-                    if (rp.tx == 0 && rp.dw != rp.sw && rp.dh != rp.sh) {
+                    if (rp.tx16 == 0 && rp.dw != rp.sw && rp.dh != rp.sh) {
                         rp.tmp_off = scratch_need;
                         scratch_need = align_up(scratch_need + (size_t)rp.dw * rp.sh * 4 + kGuard, kPixelAlign);
                     }
@@ -688,7 +739,7 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                               sizeof(Layer) * P->layers.size(), hipMemcpyHostToDevice));
         if (!P->pt.fused.empty())
             HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_f, P->pt.fused.data(),
-                              sizeof(RsFused) * P->pt.fused.size(), hipMemcpyHostToDevice));
+                              sizeof(RsMfma) * P->pt.fused.size(), hipMemcpyHostToDevice));
         if (!P->pt.h.empty())
             HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_h, P->pt.h.data(),
                               sizeof(RsJob) * P->pt.h.size(), hipMemcpyHostToDevice));
@@ -746,7 +797,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     } else {
         dp = static_cast<char *>(slot->dev);
         if (!P->layers.empty()) memcpy(hp + P->off_layers, P->layers.data(), sizeof(Layer) * P->layers.size());
-        if (!P->pt.fused.empty()) memcpy(hp + P->off_f, P->pt.fused.data(), sizeof(RsFused) * P->pt.fused.size());
+        if (!P->pt.fused.empty()) memcpy(hp + P->off_f, P->pt.fused.data(), sizeof(RsMfma) * P->pt.fused.size());
         if (!P->pt.h.empty()) memcpy(hp + P->off_h, P->pt.h.data(), sizeof(RsJob) * P->pt.h.size());
         if (!P->pt.v.empty()) memcpy(hp + P->off_v, P->pt.v.data(), sizeof(RsJob) * P->pt.v.size());
     }
@@ -757,7 +808,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     const bool prof = ctx->profiling && ctx->prof_calls < ctx->prof_max;
     hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], stream));
-    HIP_TRY(launch_resample_fused(reinterpret_cast<const RsFused *>(dp + P->off_f), (int)P->pt.fused.size(),
+    HIP_TRY(launch_resample_mfma(reinterpret_cast<const RsMfma *>(dp + P->off_f), (int)P->pt.fused.size(),
                                   P->pt.fused_max_tiles, P->pt.fused_lds, stream));
     HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + P->off_h), (int)P->pt.h.size(),
                               P->pt.max_h_out_w, P->pt.max_h_rows, stream));
@@ -885,23 +936,23 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
     rp.dst_ptr = reinterpret_cast<uint64_t>(dst_dev);
     if (int rc = choose_fused(ctx, &rp, filter)) return rc;
     size_t need = 0;
-    if (rp.tx == 0 && dst_w != src_w && dst_h != src_h) need = (size_t)dst_w * src_h * 4 + kGuard;
+    if (rp.tx16 == 0 && dst_w != src_w && dst_h != src_h) need = (size_t)dst_w * src_h * 4 + kGuard;
     if (int rc = ensure_arena(ctx, need)) return rc;
     PassTables pt;
     std::vector<ResizePlan> plans{rp};
     if (int rc = plan_passes(ctx, plans, filter, ctx->arena, &pt)) return rc;
-    const size_t off_v = 64, off_f = 128, total = 128 + sizeof(RsFused);
+    const size_t off_v = 64, off_f = 128, total = 128 + sizeof(RsMfma);
     Slot *slot = nullptr;
     if (int rc = acquire_slot(ctx, total, &slot)) return rc;
     char *hp = static_cast<char *>(slot->host);
     if (!pt.h.empty()) memcpy(hp, pt.h.data(), sizeof(RsJob));
     if (!pt.v.empty()) memcpy(hp + off_v, pt.v.data(), sizeof(RsJob));
-    if (!pt.fused.empty()) memcpy(hp + off_f, pt.fused.data(), sizeof(RsFused));
+    if (!pt.fused.empty()) memcpy(hp + off_f, pt.fused.data(), sizeof(RsMfma));
     HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, total, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(slot->ev, stream));
     slot->pending = true;
     char *dp = static_cast<char *>(slot->dev);
-    HIP_TRY(launch_resample_fused(reinterpret_cast<const RsFused *>(dp + off_f), (int)pt.fused.size(),
+    HIP_TRY(launch_resample_mfma(reinterpret_cast<const RsMfma *>(dp + off_f), (int)pt.fused.size(),
                                   pt.fused_max_tiles, pt.fused_lds, stream));
     HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp), (int)pt.h.size(), pt.max_h_out_w,
                               pt.max_h_rows, stream));

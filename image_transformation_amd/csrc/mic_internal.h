@@ -71,25 +71,26 @@ struct alignas(16) RsJob {
 };
 static_assert(sizeof(RsJob) == 64, "RsJob layout");
 
-// One layer resized by the fused kernel: both axes in one launch, source tile and 8-bit
-// intermediate in LDS.  k? == 0 means that axis keeps its size (Pillow skips that pass).
-struct alignas(16) RsFused {
+// One layer resized by the MFMA kernel: both axes in one launch, source planes and the 8-bit
+// intermediate in LDS.  Axis tables are the fragment form of resample_coeffs.h (AxisFrags); an axis
+// that keeps its size gets the identity table (one tap of weight 1.0: the pass Pillow skips).
+struct alignas(16) RsMfma {
     uint64_t src, dst;
-    uint64_t hbounds, hcoeffs;  // [dw][2], [dw][kx] (NOT transposed; the tile's slice is staged in LDS)
-    uint64_t vbounds, vcoeffs;  // [dh][2], [dh][ky]
+    uint64_t hmeta, hbias, hfrag;  // horizontal axis: [xtiles][4] int32, [16 xtiles] int32, fragments
+    uint64_t vmeta, vbias, vfrag;  // vertical axis
     int32_t sw, sh, dw, dh;
-    int32_t kx, ky;
-    int32_t tx, ty;             // output tile
+    int32_t tx16, ty16;            // workgroup tile in units of 16 output samples
     int32_t tiles_x, tiles_y;
-    int32_t max_c, max_r;       // source window capacity of a tile (columns, rows)
-    int32_t pad[4];
+    int32_t pitch_c, pitch_r;      // bytes per row of a source plane / per column of an intermediate plane
+    int32_t rows16;                // rows of a source plane (multiple of 16)
+    int32_t pad;
 };
-static_assert(sizeof(RsFused) == 112, "RsFused layout");
-inline size_t rs_fused_lds_bytes(int max_c, int max_r, int tx, int ty, int kx, int ky) {
-    return 4 * ((size_t)max_r * max_c + (size_t)max_r * tx + (size_t)kx * tx + (size_t)ty * ky + 2 * (size_t)tx +
-                2 * (size_t)ty);
+static_assert(sizeof(RsMfma) == 112, "RsMfma layout");
+inline size_t rs_mfma_lds_bytes(int rows16, int pitch_c, int tx16, int pitch_r) {
+    return 4 * ((size_t)rows16 * pitch_c + (size_t)16 * tx16 * pitch_r);
 }
-constexpr size_t kRsFusedMaxLds = 60 * 1024;
+constexpr size_t kRsMfmaPreferredLds = 80 * 1024;  // two workgroups per CU (160 KB of LDS)
+constexpr size_t kRsMfmaMaxLds = 150 * 1024;       // last resort before the two-pass fallback
 
 // ---- launchers (defined next to their kernels) -----------------------------------------------
 // The job table is sorted by kernel class; class_end[c] = one past the last job of class c for
@@ -101,8 +102,8 @@ hipError_t launch_resample_h(const RsJob *jobs_dev, int n_jobs, int max_out_w, i
                              hipStream_t stream);
 hipError_t launch_resample_v(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_out_h,
                              hipStream_t stream);
-hipError_t launch_resample_fused(const RsFused *jobs_dev, int n_jobs, int max_tiles, size_t lds_bytes,
-                                 hipStream_t stream);
+hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int max_tiles, size_t lds_bytes,
+                                hipStream_t stream);
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);
 hipError_t launch_gradient(void *out, int W, int H, const uint8_t c1[3], const uint8_t c2[3], int vertical,
                            hipStream_t stream);

@@ -6,6 +6,7 @@
 // point.  Doing that here, once per (in, out, filter) axis, leaves pure int32 work to the GPU.
 #include "resample_coeffs.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace mic {
@@ -58,6 +59,66 @@ AxisTable build_axis_table(int in_size, int out_size, int filter) {
         t.bounds[2 * o + 1] = n;
     }
     return t;
+}
+
+AxisTable identity_axis_table(int size) {
+    AxisTable t;
+    t.out_size = size;
+    t.ksize = 1;
+    t.bounds.resize(static_cast<size_t>(size) * 2);
+    t.coeffs.assign(static_cast<size_t>(size), 1 << 22);  // clip8((2^21 + s * 2^22) >> 22) == s
+    for (int o = 0; o < size; ++o) {
+        t.bounds[2 * o] = o;
+        t.bounds[2 * o + 1] = 1;
+    }
+    return t;
+}
+
+AxisFrags build_axis_frags(const AxisTable &t) {
+    AxisFrags f;
+    f.tiles = (t.out_size + 15) / 16;
+    f.meta.assign(static_cast<size_t>(f.tiles) * 4, 0);
+    f.bias.assign(static_cast<size_t>(f.tiles) * 16, 0);
+    size_t chunks = 0;
+    for (int tile = 0; tile < f.tiles; ++tile) {
+        const int o0 = tile * 16, o1 = std::min(t.out_size, o0 + 16);
+        int lo = t.bounds[2 * o0], hi = lo;
+        for (int o = o0; o < o1; ++o) {
+            lo = std::min(lo, t.bounds[2 * o]);
+            hi = std::max(hi, t.bounds[2 * o] + t.bounds[2 * o + 1]);
+        }
+        const int ws = lo & ~15;
+        const int n_chunks = std::max(1, (hi - ws + 63) / 64);
+        f.meta[4 * tile + 0] = ws;
+        f.meta[4 * tile + 1] = n_chunks;
+        f.meta[4 * tile + 2] = static_cast<int32_t>(chunks);
+        f.meta[4 * tile + 3] = hi;
+        f.max_chunks = std::max(f.max_chunks, n_chunks);
+        f.frags.resize((chunks + n_chunks) * 3 * 64 * 16, 0);
+        for (int o = o0; o < o1; ++o) {
+            const int first = t.bounds[2 * o], n = t.bounds[2 * o + 1];
+            const int32_t *row = &t.coeffs[static_cast<size_t>(o) * t.ksize];
+            int64_t sum = 0;
+            for (int k = 0; k < n; ++k) {
+                const int32_t c = row[k];
+                sum += c;
+                const int32_t d0 = ((c + 128) & 255) - 128;
+                const int32_t c1 = (c - d0) >> 8;
+                const int32_t d1 = ((c1 + 128) & 255) - 128;
+                const int32_t d2 = (c1 - d1) >> 8;  // |c| < 2^23 keeps it a signed byte
+                const int pos = first + k - ws;     // window position of this tap
+                const int chunk = pos / 64, h = (pos % 64) / 16, j = pos % 16;
+                const int lane = 16 * h + (o - o0);
+                int8_t *base = &f.frags[((chunks + chunk) * 3 * 64 + lane) * 16 + j];
+                base[0 * 64 * 16] = static_cast<int8_t>(d0);
+                base[1 * 64 * 16] = static_cast<int8_t>(d1);
+                base[2 * 64 * 16] = static_cast<int8_t>(d2);
+            }
+            f.bias[o] = static_cast<int32_t>((1 << 21) + 128 * sum);
+        }
+        chunks += n_chunks;
+    }
+    return f;
 }
 
 std::vector<int32_t> transpose_coeffs(const AxisTable &t) {

@@ -13,6 +13,25 @@ struct AxisTable {
 };
 
 AxisTable build_axis_table(int in_size, int out_size, int filter);
+AxisTable identity_axis_table(int size);  // one tap of weight 1.0 per sample: the pass Pillow skips
+
+// The same axis laid out for the MFMA resample kernel (kernels_resample.hip): output samples in
+// tiles of 16, each tile's taps as i8 operand fragments of v_mfma_i32_16x16x64_i8.
+//   meta  [tiles][4]   : window start (first tap of the tile, rounded down to 16), 64-tap chunks,
+//                        index of the tile's first chunk in `frags`, one past the tile's last tap
+//   bias  [tiles * 16] : 2^21 (Pillow's rounding) + 128 * sum of the sample's taps (samples are
+//                        stored as s - 128 so that they are signed bytes)
+//   frags [chunks][3][64][16] bytes: digit d (c = d0 + 256 d1 + 65536 d2, each digit a signed byte)
+//                        of the tap that output sample 16 t + (lane & 15) applies to window
+//                        position 64 chunk + 16 (lane >> 4) + j; zero outside the sample's taps.
+struct AxisFrags {
+    int tiles = 0;
+    int max_chunks = 0;  // most chunks any tile has
+    std::vector<int32_t> meta;
+    std::vector<int32_t> bias;
+    std::vector<int8_t> frags;
+};
+AxisFrags build_axis_frags(const AxisTable &t);
 std::vector<int32_t> transpose_coeffs(const AxisTable &t);  // -> [ksize][out_size]
 void thumbnail_size(int w, int h, int req_w, int req_h, int *out_w, int *out_h);
 
