@@ -40,6 +40,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+           # MFMA accumulators in VGPRs: the resample kernel's epilogues read every accumulator with
+           # VALU instructions, which cannot address AGPRs (one v_accvgpr_read per value otherwise)
+           "-mllvm", "-amdgpu-mfma-vgpr-form",
            "-o", LIB] + os.environ.get("MIC_EXTRA_CFLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -45,6 +45,16 @@ __device__ __forceinline__ uint32_t unpremultiply(uint32_t p) {
     return r | (g << 8) | (b << 16) | (a << 24);
 }
 
+__device__ __forceinline__ uint32_t unpremultiply_with(uint32_t p, const uint32_t *table) {
+    const uint32_t a = p >> 24;
+    if (a == 0u || a == 255u) return p;
+    const uint32_t R = table[a];
+    const uint32_t r = min(255u, __umulhi((p & 255u) << 8, R));
+    const uint32_t g = min(255u, __umulhi(p & 0xFF00u, R));
+    const uint32_t b = min(255u, __umulhi((p >> 8) & 0xFF00u, R));
+    return r | (g << 8) | (b << 16) | (a << 24);
+}
+
 __device__ __forceinline__ uint32_t clip8(int32_t v) {
     v >>= kPrecisionBits;  // arithmetic shift, like Pillow's clip8 lookup index
     // hipcc (ROCm 7.2, gfx950) fuses "shift, clamp to 0..255, pack" into v_ashr_pk_u8_i32 and then
@@ -151,12 +161,14 @@ __device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t
     return __builtin_amdgcn_perm(hi, lo, sel);
 }
 
-// Convert.c rgbA2rgba on two channels at once: x holds two bytes in 16-bit lanes (0x00XX00YY), the
-// result the two products div255(c * a + 128) in the same lanes.  No lane can carry into the other:
-// c * a + 128 <= 65153 and adding (t >> 8) <= 254 stays below 65536.
-__device__ __forceinline__ uint32_t premultiply2(uint32_t x, uint32_t a) {
-    const uint32_t t = __umul24(x, a) + 0x00800080u;
-    return ((((t >> 8) & 0x00FF00FFu) + t) >> 8) & 0x00FF00FFu;
+// Convert.c rgbA2rgba on two channels at once: x holds two bytes in 16-bit lanes (0x00XX00YY); the
+// two results div255(c * a + 128) = (t + (t >> 8)) >> 8 are left in BYTES 1 AND 3 of the returned
+// word (bytes 0 and 2 are rounding residue) -- the planarising v_perm picks them from there, which
+// saves the final shift+mask.  No lane can carry into the other: c * a + 128 <= 65153 and adding
+// (t >> 8) <= 254 stays below 65536.  Three instructions for two channels.
+__device__ __forceinline__ uint32_t premultiply2_hi(uint32_t x, uint32_t a) {
+    const uint32_t t = __umul24(x, a) + 0x00800080u;            // v_mad_u32_u24
+    return t + byte_perm(t, t, 0x0c030c01u);                     // + {t.b1, 0, t.b3, 0}
 }
 
 // clip8 of four 32-bit sums -> four bytes of one word, byte i from v[i].  v_ashr_pk_u8_i32 shifts,
@@ -170,7 +182,7 @@ __device__ __forceinline__ uint32_t clip8x4(int v0, int v1, int v2, int v3) {
 }
 
 __device__ __forceinline__ int combine(int a0, int a1, int a2) {
-    return (int)((uint32_t)a0 + ((uint32_t)a1 << 8) + ((uint32_t)a2 << 16));
+    return (int)((((((uint32_t)a2 << 8) + (uint32_t)a1)) << 8) + (uint32_t)a0);  // two v_lshl_add_u32
 }
 
 __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__restrict__ jobs) {
@@ -194,6 +206,8 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__rest
     const int plane_m = 16 * J.tx16 * J.pitch_r;    // bytes per intermediate plane
     uint8_t *srcP = lds8;                           // [4][rows16][pitch_c]
     uint8_t *midT = lds8 + 4 * plane_s;             // [4][16 tx16][pitch_r]
+    __shared__ uint32_t recip[256];                 // unpremultiply reciprocals: an LDS read, not a memory round trip
+    recip[tid] = kUnpremul.r[tid];
 
     // ---- 1. source window -> premultiplied signed-byte planes.  Items = (row, group of 4 columns),
     // dealt round-robin to the 256 threads; four 16-byte loads are in flight per thread.  The load
@@ -231,16 +245,17 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__rest
                     p3 = 0u;
                 }
                 const uint32_t px[4] = {p0, p1, p2, p3};
-                uint32_t rb[4], ga[4];
+                uint32_t rb[4], ga[4];  // premultiplied {R, B} and {G, A} in bytes 1 and 3
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t a = px[j] >> 24;
-                    rb[j] = premultiply2(px[j] & 0x00FF00FFu, a);
-                    ga[j] = premultiply2(((px[j] >> 8) & 0xFFu) | 0x00FF0000u, a);  // div255(255 a + 128) == a
+                    rb[j] = premultiply2_hi(px[j] & 0x00FF00FFu, a);
+                    // {G, 255}: div255(255 a + 128) == a keeps the alpha byte itself
+                    ga[j] = premultiply2_hi(byte_perm(px[j], px[j], 0x0c0d0c01u), a);
                 }
                 // 4 px x 2 lanes -> one word per plane: {c0, c1, c2, c3} of the four pixels
-                const uint32_t rb01 = byte_perm(rb[1], rb[0], 0x06020400u), rb23 = byte_perm(rb[3], rb[2], 0x06020400u);
-                const uint32_t ga01 = byte_perm(ga[1], ga[0], 0x06020400u), ga23 = byte_perm(ga[3], ga[2], 0x06020400u);
+                const uint32_t rb01 = byte_perm(rb[1], rb[0], 0x07030501u), rb23 = byte_perm(rb[3], rb[2], 0x07030501u);
+                const uint32_t ga01 = byte_perm(ga[1], ga[0], 0x07030501u), ga23 = byte_perm(ga[3], ga[2], 0x07030501u);
                 uint32_t *dst = reinterpret_cast<uint32_t *>(srcP + irr[k] * J.pitch_c + cc);
                 dst[0 * (plane_s >> 2)] = byte_perm(rb23, rb01, 0x05040100u) ^ 0x80808080u;  // R
                 dst[1 * (plane_s >> 2)] = byte_perm(ga23, ga01, 0x05040100u) ^ 0x80808080u;  // G
@@ -258,8 +273,10 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__rest
         const int n_rt = (R + 15) >> 4;
         int cur = -1, bias = 0;
         v4i m = {0, 0, 0, 0}, b0 = m, b1 = m, b2 = m;
-        for (int pair = wave; pair < n_xt * n_rt; pair += 4) {
-            const int xi = pair / n_rt, rt = pair - xi * n_rt;
+        int xi = wave / n_rt, rt = wave - xi * n_rt;  // pair = wave, wave + 4, ...: (x-tile, row-tile)
+        for (; xi < n_xt; rt += 4) {
+            while (rt >= n_rt) { rt -= n_rt; ++xi; }
+            if (xi >= n_xt) break;
             if (xi != cur) {  // wave-uniform: a wave's consecutive pairs mostly share the x-tile
                 cur = xi;
                 m = hmeta[xt0 + xi];
@@ -315,8 +332,10 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__rest
         gptr dst = reinterpret_cast<gptr>(J.dst);
         int cur = -1;
         v4i m = {0, 0, 0, 0}, a0 = m, a1 = m, a2 = m, bias = m;
-        for (int pair = wave; pair < n_yt * n_xt; pair += 4) {
-            const int yi = pair / n_xt, xi = pair - yi * n_xt;
+        int yi = wave / n_xt, xi = wave - yi * n_xt;  // pair = wave, wave + 4, ...: (y-tile, x-tile)
+        for (; yi < n_yt; xi += 4) {
+            while (xi >= n_xt) { xi -= n_xt; ++yi; }
+            if (yi >= n_yt) break;
             if (yi != cur) {
                 cur = yi;
                 m = vmeta[yt0 + yi];
@@ -368,7 +387,7 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__rest
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int oy = (yt0 + yi) * 16 + 4 * lh + r;
-                if (ox < J.dw && oy < J.dh) dst[(size_t)oy * J.dw + ox] = unpremultiply(px[r]);
+                if (ox < J.dw && oy < J.dh) dst[(size_t)oy * J.dw + ox] = unpremultiply_with(px[r], recip);
             }
         }
     }

@@ -493,13 +493,7 @@ void window_extents(const std::vector<int32_t> &meta, int tiles, int per, int *t
     }
 }
 
-// LDS rows are read 16 bytes per lane by lanes that differ in the row: an odd number of 16-byte
-// units per row spreads them over the banks.
-int odd_pitch(int bytes) {
-    int p = (bytes + 15) / 16;
-    if ((p & 1) == 0) ++p;
-    return 16 * p;
-}
+int round16(int v) { return (v + 15) / 16 * 16; }
 
 // Pick the workgroup tile of the MFMA kernel for one layer: the biggest of a short list whose
 // source planes + intermediate planes fit LDS, preferring sizes that let two workgroups share a CU.
@@ -516,7 +510,11 @@ int choose_fused(mic_ctx *ctx, ResizePlan *p, int filter) {
             int tc, nc, tr, nr;
             window_extents(*fh.meta_host, fh.tiles, t[0], &tc, &nc);
             window_extents(*fv.meta_host, fv.tiles, t[1], &tr, &nr);
-            const int pitch_c = odd_pitch(tc), pitch_r = odd_pitch(tr), rows16 = (std::min(nr, p->sh) + 15) / 16 * 16;
+            // Pitches cover what a tile needs, not what its 64-sample chunks touch: a read past the
+            // end of a row lands in the next row (or in the 64 bytes of slack after the last one)
+            // and meets zero tap digits.
+            (void)tc; (void)tr;
+            const int pitch_c = round16(nc), rows16 = round16(nr), pitch_r = rows16;
             if (rs_mfma_lds_bytes(rows16, pitch_c, t[0], pitch_r) <= cap) {
                 p->tx16 = t[0]; p->ty16 = t[1]; p->pitch_c = pitch_c; p->pitch_r = pitch_r; p->rows16 = rows16;
                 return MIC_OK;

@@ -87,9 +87,9 @@ struct alignas(16) RsMfma {
 };
 static_assert(sizeof(RsMfma) == 112, "RsMfma layout");
 inline size_t rs_mfma_lds_bytes(int rows16, int pitch_c, int tx16, int pitch_r) {
-    return 4 * ((size_t)rows16 * pitch_c + (size_t)16 * tx16 * pitch_r);
+    return 4 * ((size_t)rows16 * pitch_c + (size_t)16 * tx16 * pitch_r) + 64;  // + slack for chunk over-reads
 }
-constexpr size_t kRsMfmaPreferredLds = 80 * 1024;  // two workgroups per CU (160 KB of LDS)
+constexpr size_t kRsMfmaPreferredLds = 52 * 1024;  // three workgroups per CU (160 KB of LDS, 1 KB static each)
 constexpr size_t kRsMfmaMaxLds = 150 * 1024;       // last resort before the two-pass fallback
 
 // ---- launchers (defined next to their kernels) -----------------------------------------------
