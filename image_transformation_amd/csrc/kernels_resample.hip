@@ -185,6 +185,56 @@ __device__ __forceinline__ int combine(int a0, int a1, int a2) {
     return (int)((((((uint32_t)a2 << 8) + (uint32_t)a1)) << 8) + (uint32_t)a0);  // two v_lshl_add_u32
 }
 
+// One 16 x 16 output tile: acc[channel][digit] = bias + sum over the window's 64-sample chunks of
+// data x tap-digit fragments.  DATA_IS_A: the LDS bytes are the A operand (horizontal pass: rows of
+// a source plane), otherwise B (vertical pass: columns of an intermediate plane).  f = the first
+// chunk's fragments (kept in registers by the caller), fbase = where the tile's fragments start.
+template <bool DATA_IS_A>
+__device__ __forceinline__ void tile_mfma(v4i (&acc)[4][3], const uint8_t *data, int plane, const v4i (&f)[3],
+                                          gv4ptr fbase, int n_chunks, v4i bias) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const v4i d = *reinterpret_cast<const v4i *>(data + c * plane);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const v4i init = k == 0 ? bias : v4i{0, 0, 0, 0};
+            acc[c][k] = DATA_IS_A ? __builtin_amdgcn_mfma_i32_16x16x64_i8(d, f[k], init, 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_i32_16x16x64_i8(f[k], d, init, 0, 0, 0);
+        }
+    }
+    for (int ch = 1; ch < n_chunks; ++ch) {  // windows wider than 64 samples (shrinks below ~1/3)
+        const v4i e[3] = {fbase[(ch * 3 + 0) * 64], fbase[(ch * 3 + 1) * 64], fbase[(ch * 3 + 2) * 64]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const v4i d = *reinterpret_cast<const v4i *>(data + 64 * ch + c * plane);
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                acc[c][k] = DATA_IS_A ? __builtin_amdgcn_mfma_i32_16x16x64_i8(d, e[k], acc[c][k], 0, 0, 0)
+                                      : __builtin_amdgcn_mfma_i32_16x16x64_i8(e[k], d, acc[c][k], 0, 0, 0);
+        }
+    }
+}
+
+// Accumulators -> per channel one word holding the clipped bytes of the lane's 4 rows.
+__device__ __forceinline__ void tile_words(const v4i (&acc)[4][3], uint32_t (&w)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        w[c] = clip8x4(combine(acc[c][0][0], acc[c][1][0], acc[c][2][0]), combine(acc[c][0][1], acc[c][1][1], acc[c][2][1]),
+                       combine(acc[c][0][2], acc[c][1][2], acc[c][2][2]), combine(acc[c][0][3], acc[c][1][3], acc[c][2][3]));
+}
+
+// 4 channels x 4 rows -> 4 RGBA pixels (byte transpose), unpremultiply, store column ox of rows oy..oy+3.
+__device__ __forceinline__ void store_pixels(const uint32_t (&w)[4], gptr dst, int dw, int dh, int ox, int oy,
+                                             const uint32_t *recip) {
+    const uint32_t rg01 = byte_perm(w[1], w[0], 0x05010400u), rg23 = byte_perm(w[1], w[0], 0x07030602u);
+    const uint32_t ba01 = byte_perm(w[3], w[2], 0x05010400u), ba23 = byte_perm(w[3], w[2], 0x07030602u);
+    const uint32_t px[4] = {byte_perm(ba01, rg01, 0x05040100u), byte_perm(ba01, rg01, 0x07060302u),
+                            byte_perm(ba23, rg23, 0x05040100u), byte_perm(ba23, rg23, 0x07060302u)};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (ox < dw && oy + r < dh) dst[(size_t)(oy + r) * dw + ox] = unpremultiply_with(px[r], recip);
+}
+
 __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__restrict__ jobs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
     const RsMfma J = jobs[blockIdx.y];
@@ -266,128 +316,69 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__rest
     }
     __syncthreads();
 
-    // ---- 2. horizontal pass: window rows -> 8-bit intermediate, transposed
+    // ---- 2. horizontal pass: window rows -> 8-bit intermediate, transposed.  A wave keeps one
+    // x-tile (its tap fragments stay in registers) and walks the row tiles two at a time: the second
+    // tile's MFMAs run in the matrix pipe while the VALU does the first tile's epilogue.
     {
-        gciptr hbias = reinterpret_cast<gciptr>(J.hbias);
-        gv4ptr hfrag = reinterpret_cast<gv4ptr>(J.hfrag);
-        const int n_rt = (R + 15) >> 4;
-        int cur = -1, bias = 0;
-        v4i m = {0, 0, 0, 0}, b0 = m, b1 = m, b2 = m;
-        int xi = wave / n_rt, rt = wave - xi * n_rt;  // pair = wave, wave + 4, ...: (x-tile, row-tile)
-        for (; xi < n_xt; rt += 4) {
-            while (rt >= n_rt) { rt -= n_rt; ++xi; }
-            if (xi >= n_xt) break;
-            if (xi != cur) {  // wave-uniform: a wave's consecutive pairs mostly share the x-tile
-                cur = xi;
-                m = hmeta[xt0 + xi];
-                bias = hbias[(xt0 + xi) * 16 + l15];
-                gv4ptr f = hfrag + (size_t)m[2] * 3 * 64 + lane;
-                b0 = f[0]; b1 = f[64]; b2 = f[128];
-            }
-            const int off = m[0] - c_lo;  // multiple of 16
-            v4i acc[4][3];
+        const int groups = 4 / n_xt;  // waves per x-tile (n_xt <= 4)
+        if (wave < n_xt * groups) {
+            const int xi = wave % n_xt, sub = wave / n_xt;
+            const int n_rt = (R + 15) >> 4;
+            const v4i m = hmeta[xt0 + xi];
+            const int b = reinterpret_cast<gciptr>(J.hbias)[(xt0 + xi) * 16 + l15];
+            const v4i bias = {b, b, b, b};
+            gv4ptr fbase = reinterpret_cast<gv4ptr>(J.hfrag) + (size_t)m[2] * 3 * 64 + lane;
+            const v4i f[3] = {fbase[0], fbase[64], fbase[128]};
+            const uint8_t *a0 = srcP + l15 * J.pitch_c + (m[0] - c_lo) + 16 * lh;      // + 16 rt pitch_c
+            uint8_t *m0 = midT + (xi * 16 + l15) * J.pitch_r + 4 * lh;                 // + 16 rt
+            for (int rt = sub; rt < n_rt; rt += 2 * groups) {
+                const int rt2 = rt + groups;
+                const bool two = rt2 < n_rt;  // wave-uniform
+                v4i acc[4][3], acc2[4][3];
+                tile_mfma<true>(acc, a0 + rt * 16 * J.pitch_c, plane_s, f, fbase, m[1], bias);
+                if (two) tile_mfma<true>(acc2, a0 + rt2 * 16 * J.pitch_c, plane_s, f, fbase, m[1], bias);
+                // D[row = 4 lh + reg (window row)][col = l15 (x)]: 4 consecutive rows of one column
+                uint32_t w[4];
+                tile_words(acc, w);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc[c][0] = v4i{bias, bias, bias, bias};
-                acc[c][1] = v4i{0, 0, 0, 0};
-                acc[c][2] = v4i{0, 0, 0, 0};
-            }
-            const uint8_t *arow = srcP + (rt * 16 + l15) * J.pitch_c + off + 16 * lh;
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m0 + rt * 16 + c * plane_m) = w[c] ^ 0x80808080u;
+                if (two) {
+                    tile_words(acc2, w);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const v4i a = *reinterpret_cast<const v4i *>(arow + c * plane_s);
-                acc[c][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b0, acc[c][0], 0, 0, 0);
-                acc[c][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b1, acc[c][1], 0, 0, 0);
-                acc[c][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b2, acc[c][2], 0, 0, 0);
-            }
-            for (int ch = 1; ch < m[1]; ++ch) {  // windows wider than 64 samples (shrinks below ~1/3)
-                gv4ptr f = hfrag + (size_t)(m[2] + ch) * 3 * 64 + lane;
-                const v4i e0 = f[0], e1 = f[64], e2 = f[128];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const v4i a = *reinterpret_cast<const v4i *>(arow + 64 * ch + c * plane_s);
-                    acc[c][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, e0, acc[c][0], 0, 0, 0);
-                    acc[c][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, e1, acc[c][1], 0, 0, 0);
-                    acc[c][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, e2, acc[c][2], 0, 0, 0);
+                    for (int c = 0; c < 4; ++c)
+                        *reinterpret_cast<uint32_t *>(m0 + rt2 * 16 + c * plane_m) = w[c] ^ 0x80808080u;
                 }
-            }
-            // D[row = 4 lh + reg (window row)][col = l15 (x)]: 4 consecutive rows of one column
-            uint8_t *mrow = midT + (xi * 16 + l15) * J.pitch_r + rt * 16 + 4 * lh;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const uint32_t w = clip8x4(combine(acc[c][0][0], acc[c][1][0], acc[c][2][0]),
-                                           combine(acc[c][0][1], acc[c][1][1], acc[c][2][1]),
-                                           combine(acc[c][0][2], acc[c][1][2], acc[c][2][2]),
-                                           combine(acc[c][0][3], acc[c][1][3], acc[c][2][3]));
-                *reinterpret_cast<uint32_t *>(mrow + c * plane_m) = w ^ 0x80808080u;
             }
         }
     }
     __syncthreads();
 
-    // ---- 3. vertical pass + unpremultiply + store
+    // ---- 3. vertical pass + unpremultiply + store: a wave keeps one y-tile, walks the x-tiles
     {
-        gciptr vbias = reinterpret_cast<gciptr>(J.vbias);
-        gv4ptr vfrag = reinterpret_cast<gv4ptr>(J.vfrag);
-        gptr dst = reinterpret_cast<gptr>(J.dst);
-        int cur = -1;
-        v4i m = {0, 0, 0, 0}, a0 = m, a1 = m, a2 = m, bias = m;
-        int yi = wave / n_xt, xi = wave - yi * n_xt;  // pair = wave, wave + 4, ...: (y-tile, x-tile)
-        for (; yi < n_yt; xi += 4) {
-            while (xi >= n_xt) { xi -= n_xt; ++yi; }
-            if (yi >= n_yt) break;
-            if (yi != cur) {
-                cur = yi;
-                m = vmeta[yt0 + yi];
-                bias = *reinterpret_cast<gv4ptr>(vbias + (yt0 + yi) * 16 + 4 * lh);
-                gv4ptr f = vfrag + (size_t)m[2] * 3 * 64 + lane;
-                a0 = f[0]; a1 = f[64]; a2 = f[128];
-            }
-            const int off = m[0] - r_lo;  // multiple of 16
-            v4i acc[4][3];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc[c][0] = bias;
-                acc[c][1] = v4i{0, 0, 0, 0};
-                acc[c][2] = v4i{0, 0, 0, 0};
-            }
-            const uint8_t *bcol = midT + (xi * 16 + l15) * J.pitch_r + off + 16 * lh;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const v4i b = *reinterpret_cast<const v4i *>(bcol + c * plane_m);
-                acc[c][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b, acc[c][0], 0, 0, 0);
-                acc[c][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b, acc[c][1], 0, 0, 0);
-                acc[c][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a2, b, acc[c][2], 0, 0, 0);
-            }
-            for (int ch = 1; ch < m[1]; ++ch) {
-                gv4ptr f = vfrag + (size_t)(m[2] + ch) * 3 * 64 + lane;
-                const v4i e0 = f[0], e1 = f[64], e2 = f[128];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const v4i b = *reinterpret_cast<const v4i *>(bcol + 64 * ch + c * plane_m);
-                    acc[c][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(e0, b, acc[c][0], 0, 0, 0);
-                    acc[c][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(e1, b, acc[c][1], 0, 0, 0);
-                    acc[c][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(e2, b, acc[c][2], 0, 0, 0);
+        const int groups = 4 / n_yt;
+        if (wave < n_yt * groups) {
+            const int yi = wave % n_yt, sub = wave / n_yt;
+            const v4i m = vmeta[yt0 + yi];
+            const v4i bias = *reinterpret_cast<gv4ptr>(reinterpret_cast<gciptr>(J.vbias) + (yt0 + yi) * 16 + 4 * lh);
+            gv4ptr fbase = reinterpret_cast<gv4ptr>(J.vfrag) + (size_t)m[2] * 3 * 64 + lane;
+            const v4i f[3] = {fbase[0], fbase[64], fbase[128]};
+            const uint8_t *b0 = midT + l15 * J.pitch_r + (m[0] - r_lo) + 16 * lh;      // + 16 xi pitch_r
+            gptr dst = reinterpret_cast<gptr>(J.dst);
+            const int oy0 = (yt0 + yi) * 16 + 4 * lh;
+            for (int xi = sub; xi < n_xt; xi += 2 * groups) {
+                const int xi2 = xi + groups;
+                const bool two = xi2 < n_xt;
+                v4i acc[4][3], acc2[4][3];
+                tile_mfma<false>(acc, b0 + xi * 16 * J.pitch_r, plane_m, f, fbase, m[1], bias);
+                if (two) tile_mfma<false>(acc2, b0 + xi2 * 16 * J.pitch_r, plane_m, f, fbase, m[1], bias);
+                // D[row = 4 lh + reg (output row)][col = l15 (x)]: per channel the bytes of 4 rows
+                uint32_t w[4];
+                tile_words(acc, w);
+                store_pixels(w, dst, J.dw, J.dh, (xt0 + xi) * 16 + l15, oy0, recip);
+                if (two) {
+                    tile_words(acc2, w);
+                    store_pixels(w, dst, J.dw, J.dh, (xt0 + xi2) * 16 + l15, oy0, recip);
                 }
-            }
-            // D[row = 4 lh + reg (output row)][col = l15 (x)]: per channel the bytes of 4 rows
-            uint32_t w[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                w[c] = clip8x4(combine(acc[c][0][0], acc[c][1][0], acc[c][2][0]),
-                               combine(acc[c][0][1], acc[c][1][1], acc[c][2][1]),
-                               combine(acc[c][0][2], acc[c][1][2], acc[c][2][2]),
-                               combine(acc[c][0][3], acc[c][1][3], acc[c][2][3]));
-            // 4 channels x 4 rows -> 4 RGBA pixels (byte transpose)
-            const uint32_t rg01 = byte_perm(w[1], w[0], 0x05010400u), rg23 = byte_perm(w[1], w[0], 0x07030602u);
-            const uint32_t ba01 = byte_perm(w[3], w[2], 0x05010400u), ba23 = byte_perm(w[3], w[2], 0x07030602u);
-            const uint32_t px[4] = {byte_perm(ba01, rg01, 0x05040100u), byte_perm(ba01, rg01, 0x07060302u),
-                                    byte_perm(ba23, rg23, 0x05040100u), byte_perm(ba23, rg23, 0x07060302u)};
-            const int ox = (xt0 + xi) * 16 + l15;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int oy = (yt0 + yi) * 16 + 4 * lh + r;
-                if (ox < J.dw && oy < J.dh) dst[(size_t)oy * J.dw + ox] = unpremultiply_with(px[r], recip);
             }
         }
     }

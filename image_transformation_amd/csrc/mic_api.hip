@@ -505,7 +505,8 @@ int choose_fused(mic_ctx *ctx, ResizePlan *p, int filter) {
     static const int kTiles[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
     p->tx16 = 0;
     if ((int64_t)p->sw * p->sh < 4) return MIC_OK;  // the kernel's 16-byte loads need 4 pixels to clamp into
-    for (const size_t cap : {kRsMfmaPreferredLds, kRsMfmaMaxLds}) {
+    static const size_t pref = getenv("MIC_RS_LDS_KB") ? (size_t)atoi(getenv("MIC_RS_LDS_KB")) * 1024 : kRsMfmaPreferredLds;
+    for (const size_t cap : {pref, kRsMfmaMaxLds}) {
         for (const auto &t : kTiles) {
             int tc, nc, tr, nr;
             window_extents(*fh.meta_host, fh.tiles, t[0], &tc, &nc);
