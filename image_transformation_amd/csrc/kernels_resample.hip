@@ -9,6 +9,8 @@
 // passes are pure integer arithmetic and bit-exact.
 //
 // One launch processes every resampled layer of a composite call (blockIdx.z = layer).
+#include <algorithm>
+
 #include "mic_internal.h"
 
 namespace mic {
@@ -45,13 +47,21 @@ __device__ __forceinline__ uint32_t unpremultiply(uint32_t p) {
     return r | (g << 8) | (b << 16) | (a << 24);
 }
 
-__device__ __forceinline__ uint32_t unpremultiply_with(uint32_t p, const uint32_t *table) {
+// The same in float, for the MFMA kernel (v_mul_hi_u32 is a quarter-rate instruction, and this runs
+// once per output pixel): floor(c' * F[a]) == floor(255 c' / a) for every c' in 0..255 once clamped to
+// 255, with F[a] = 255/a rounded to float and bumped up one ulp -- the product can only exceed the
+// exact quotient, by < 2^-14, and the quotient's fractional part is <= 1 - 1/254 (or the value is
+// >= 256 and clamps).  Checked exhaustively in tests/test_blend_identities.py with numpy float32.
+__device__ __forceinline__ float unpremul_factor(uint32_t a) {
+    return __uint_as_float(__float_as_uint(__fdiv_rn(255.0f, (float)a)) + 1u);
+}
+__device__ __forceinline__ uint32_t unpremultiply_with(uint32_t p, const float *table) {
     const uint32_t a = p >> 24;
     if (a == 0u || a == 255u) return p;
-    const uint32_t R = table[a];
-    const uint32_t r = min(255u, __umulhi((p & 255u) << 8, R));
-    const uint32_t g = min(255u, __umulhi(p & 0xFF00u, R));
-    const uint32_t b = min(255u, __umulhi((p >> 8) & 0xFF00u, R));
+    const float F = table[a];
+    const uint32_t r = min(255u, (uint32_t)((float)(p & 255u) * F));
+    const uint32_t g = min(255u, (uint32_t)((float)((p >> 8) & 255u) * F));
+    const uint32_t b = min(255u, (uint32_t)((float)((p >> 16) & 255u) * F));
     return r | (g << 8) | (b << 16) | (a << 24);
 }
 
@@ -185,6 +195,79 @@ __device__ __forceinline__ int combine(int a0, int a1, int a2) {
     return (int)((((((uint32_t)a2 << 8) + (uint32_t)a1)) << 8) + (uint32_t)a0);  // two v_lshl_add_u32
 }
 
+// Phase 1 of the MFMA kernel: R rows x C columns of the source, starting at pixel index `origin`,
+// go to LDS premultiplied and split into four planes of signed bytes (s - 128).  Items = (row, group
+// of 4 columns), dealt round-robin to the 256 threads, indices advanced incrementally (no per-item
+// multiply or divide); four 16-byte loads are in flight per thread and the loads are unconditional
+// (index clamped to last4 = pixels - 4; the host keeps images smaller than 4 px off this kernel).
+// EDGE: C is not a multiple of 4 (only when the window ends at the image's right edge): the last
+// group of each row is re-read pixel by pixel.
+template <bool EDGE>
+__device__ __forceinline__ void load_window(gcptr src, int sw, int last4, int origin, int R, int C, uint8_t *srcP,
+                                            int pitch_c, int plane_s, int tid) {
+    const int G = (C + 3) >> 2;
+    const int dq = 256 / G, dr = 256 - dq * G;
+    int rr = tid / G, g = tid - rr * G;
+    int gi = origin + rr * sw + 4 * g;   // pixel index in the source image
+    int lo = rr * pitch_c + 4 * g;       // byte offset in a plane
+    const int gi_step = dq * sw + 4 * dr, lo_step = dq * pitch_c + 4 * dr;
+    const int gi_wrap = sw - 4 * G, lo_wrap = pitch_c - 4 * G;
+    while (rr < R) {
+        int irr[4], ig[4], igi[4], ilo[4];
+        u32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            irr[k] = rr; ig[k] = g; igi[k] = gi; ilo[k] = lo;
+            __builtin_memcpy(&v[k], (const void *)(src + min(gi, last4)), 16);
+            rr += dq; g += dr; gi += gi_step; lo += lo_step;
+            if (g >= G) { g -= G; ++rr; gi += gi_wrap; lo += lo_wrap; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (irr[k] >= R) break;
+            uint32_t px[4] = {v[k][0], v[k][1], v[k][2], v[k][3]};
+            if (EDGE && ig[k] == G - 1) {
+                const int left = C - 4 * ig[k];  // 1..3 valid pixels
+                px[0] = src[igi[k]];
+                px[1] = left > 1 ? src[igi[k] + 1] : 0u;
+                px[2] = left > 2 ? src[igi[k] + 2] : 0u;
+                px[3] = 0u;
+            }
+            uint32_t rb[4], ga[4];  // premultiplied {R, B} and {G, A} in bytes 1 and 3
+            // Cutouts are mostly binary-alpha (the reference's bundles have no partial alpha at all):
+            // when every pixel this wave holds has alpha 0 or 255, premultiplying is a select.
+            bool binary = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) binary = binary && ((px[j] >> 24) == 0u || (px[j] >> 24) == 255u);
+            if (__all(binary)) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t keep = (uint32_t)((int32_t)px[j] >> 31);  // alpha 255 -> all ones, 0 -> zero
+                    const uint32_t q = px[j] & keep;
+                    rb[j] = (q & 0x00FF00FFu) << 8;                           // bytes 1 and 3, like the general path
+                    ga[j] = q & 0xFF00FF00u;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t a = px[j] >> 24;
+                    rb[j] = premultiply2_hi(px[j] & 0x00FF00FFu, a);
+                    // {G, 255}: div255(255 a + 128) == a keeps the alpha byte itself
+                    ga[j] = premultiply2_hi(byte_perm(px[j], px[j], 0x0c0d0c01u), a);
+                }
+            }
+            // 4 px x 2 lanes -> one word per plane: {c0, c1, c2, c3} of the four pixels
+            const uint32_t rb01 = byte_perm(rb[1], rb[0], 0x07030501u), rb23 = byte_perm(rb[3], rb[2], 0x07030501u);
+            const uint32_t ga01 = byte_perm(ga[1], ga[0], 0x07030501u), ga23 = byte_perm(ga[3], ga[2], 0x07030501u);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(srcP + ilo[k]);
+            dst[0 * (plane_s >> 2)] = byte_perm(rb23, rb01, 0x05040100u) ^ 0x80808080u;  // R
+            dst[1 * (plane_s >> 2)] = byte_perm(ga23, ga01, 0x05040100u) ^ 0x80808080u;  // G
+            dst[2 * (plane_s >> 2)] = byte_perm(rb23, rb01, 0x07060302u) ^ 0x80808080u;  // B
+            dst[3 * (plane_s >> 2)] = byte_perm(ga23, ga01, 0x07060302u) ^ 0x80808080u;  // A
+        }
+    }
+}
+
 // One 16 x 16 output tile: acc[channel][digit] = bias + sum over the window's 64-sample chunks of
 // data x tap-digit fragments.  DATA_IS_A: the LDS bytes are the A operand (horizontal pass: rows of
 // a source plane), otherwise B (vertical pass: columns of an intermediate plane).  f = the first
@@ -225,7 +308,7 @@ __device__ __forceinline__ void tile_words(const v4i (&acc)[4][3], uint32_t (&w)
 
 // 4 channels x 4 rows -> 4 RGBA pixels (byte transpose), unpremultiply, store column ox of rows oy..oy+3.
 __device__ __forceinline__ void store_pixels(const uint32_t (&w)[4], gptr dst, int dw, int dh, int ox, int oy,
-                                             const uint32_t *recip) {
+                                             const float *recip) {
     const uint32_t rg01 = byte_perm(w[1], w[0], 0x05010400u), rg23 = byte_perm(w[1], w[0], 0x07030602u);
     const uint32_t ba01 = byte_perm(w[3], w[2], 0x05010400u), ba23 = byte_perm(w[3], w[2], 0x07030602u);
     const uint32_t px[4] = {byte_perm(ba01, rg01, 0x05040100u), byte_perm(ba01, rg01, 0x07060302u),
@@ -238,7 +321,7 @@ __device__ __forceinline__ void store_pixels(const uint32_t (&w)[4], gptr dst, i
 __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__restrict__ jobs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
     const RsMfma J = jobs[blockIdx.y];
-    const int tile = blockIdx.x;
+    const int tile = J.tile0 + blockIdx.x;  // a layer is launched in slices of kRsTilesPerEntry tiles
     if (tile >= J.tiles_x * J.tiles_y) return;
     const int tyi = tile / J.tiles_x, txi = tile - tyi * J.tiles_x;
     const int xt0 = txi * J.tx16, yt0 = tyi * J.ty16;
@@ -256,64 +339,16 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__rest
     const int plane_m = 16 * J.tx16 * J.pitch_r;    // bytes per intermediate plane
     uint8_t *srcP = lds8;                           // [4][rows16][pitch_c]
     uint8_t *midT = lds8 + 4 * plane_s;             // [4][16 tx16][pitch_r]
-    __shared__ uint32_t recip[256];                 // unpremultiply reciprocals: an LDS read, not a memory round trip
-    recip[tid] = kUnpremul.r[tid];
+    __shared__ float recip[256];                    // unpremultiply factors 255/a: an LDS read per pixel
+    recip[tid] = unpremul_factor((uint32_t)tid);
 
-    // ---- 1. source window -> premultiplied signed-byte planes.  Items = (row, group of 4 columns),
-    // dealt round-robin to the 256 threads; four 16-byte loads are in flight per thread.  The load
-    // itself is unconditional (index clamped into the image); only a group cut by the image's right
-    // edge is re-read pixel by pixel.
-    {
-        gcptr src = reinterpret_cast<gcptr>(J.src);
-        const int G = (C + 3) >> 2;
-        const int dq = 256 / G, dr = 256 - dq * G;
-        const int last4 = J.sw * J.sh - 4;  // the host keeps images smaller than 4 px off this kernel
-        int rr = tid / G, g = tid - rr * G;
-        while (rr < R) {
-            int irr[4], ig[4];
-            u32x4 v[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                irr[k] = rr;
-                ig[k] = g;
-                const int idx = (r_lo + min(rr, R - 1)) * J.sw + c_lo + 4 * g;
-                __builtin_memcpy(&v[k], (const void *)(src + min(idx, last4)), 16);
-                rr += dq;
-                g += dr;
-                if (g >= G) { g -= G; ++rr; }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (irr[k] >= R) break;
-                const int cc = 4 * ig[k];
-                uint32_t p0 = v[k][0], p1 = v[k][1], p2 = v[k][2], p3 = v[k][3];
-                if (cc + 4 > C) {  // cut by the image's right edge (rare)
-                    gcptr row = src + (size_t)(r_lo + irr[k]) * J.sw + c_lo + cc;
-                    p0 = row[0];
-                    p1 = cc + 1 < C ? row[1] : 0u;
-                    p2 = cc + 2 < C ? row[2] : 0u;
-                    p3 = 0u;
-                }
-                const uint32_t px[4] = {p0, p1, p2, p3};
-                uint32_t rb[4], ga[4];  // premultiplied {R, B} and {G, A} in bytes 1 and 3
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t a = px[j] >> 24;
-                    rb[j] = premultiply2_hi(px[j] & 0x00FF00FFu, a);
-                    // {G, 255}: div255(255 a + 128) == a keeps the alpha byte itself
-                    ga[j] = premultiply2_hi(byte_perm(px[j], px[j], 0x0c0d0c01u), a);
-                }
-                // 4 px x 2 lanes -> one word per plane: {c0, c1, c2, c3} of the four pixels
-                const uint32_t rb01 = byte_perm(rb[1], rb[0], 0x07030501u), rb23 = byte_perm(rb[3], rb[2], 0x07030501u);
-                const uint32_t ga01 = byte_perm(ga[1], ga[0], 0x07030501u), ga23 = byte_perm(ga[3], ga[2], 0x07030501u);
-                uint32_t *dst = reinterpret_cast<uint32_t *>(srcP + irr[k] * J.pitch_c + cc);
-                dst[0 * (plane_s >> 2)] = byte_perm(rb23, rb01, 0x05040100u) ^ 0x80808080u;  // R
-                dst[1 * (plane_s >> 2)] = byte_perm(ga23, ga01, 0x05040100u) ^ 0x80808080u;  // G
-                dst[2 * (plane_s >> 2)] = byte_perm(rb23, rb01, 0x07060302u) ^ 0x80808080u;  // B
-                dst[3 * (plane_s >> 2)] = byte_perm(ga23, ga01, 0x07060302u) ^ 0x80808080u;  // A
-            }
-        }
-    }
+    // ---- 1. source window -> premultiplied signed-byte planes
+    if ((C & 3) == 0)
+        load_window<false>(reinterpret_cast<gcptr>(J.src), J.sw, J.sw * J.sh - 4, r_lo * J.sw + c_lo, R, C, srcP,
+                           J.pitch_c, plane_s, tid);
+    else  // the window ends at the image's right edge in the middle of a group of 4 columns
+        load_window<true>(reinterpret_cast<gcptr>(J.src), J.sw, J.sw * J.sh - 4, r_lo * J.sw + c_lo, R, C, srcP,
+                          J.pitch_c, plane_s, tid);
     __syncthreads();
 
     // ---- 2. horizontal pass: window rows -> 8-bit intermediate, transposed.  A wave keeps one
@@ -394,8 +429,11 @@ hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int max_tile
         if (e != hipSuccess) return e;
         attr_set = kRsMfmaMaxLds;
     }
-    hipLaunchKernelGGL(resample_mfma_kernel, dim3((unsigned)max_tiles, (unsigned)n_jobs), dim3(256), lds_bytes, stream,
-                       jobs_dev);
+    for (int first = 0; first < n_jobs; first += 65535) {  // grid.y limit
+        const int n = std::min(65535, n_jobs - first);
+        hipLaunchKernelGGL(resample_mfma_kernel, dim3((unsigned)max_tiles, (unsigned)n), dim3(256), lds_bytes, stream,
+                           jobs_dev + first);
+    }
     return hipGetLastError();
 }
 

@@ -505,8 +505,7 @@ int choose_fused(mic_ctx *ctx, ResizePlan *p, int filter) {
     static const int kTiles[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
     p->tx16 = 0;
     if ((int64_t)p->sw * p->sh < 4) return MIC_OK;  // the kernel's 16-byte loads need 4 pixels to clamp into
-    static const size_t pref = getenv("MIC_RS_LDS_KB") ? (size_t)atoi(getenv("MIC_RS_LDS_KB")) * 1024 : kRsMfmaPreferredLds;
-    for (const size_t cap : {pref, kRsMfmaMaxLds}) {
+    for (const size_t cap : {kRsMfmaPreferredLds, kRsMfmaMaxLds}) {
         for (const auto &t : kTiles) {
             int tc, nc, tr, nr;
             window_extents(*fh.meta_host, fh.tiles, t[0], &tc, &nc);
@@ -542,8 +541,9 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             f.tx16 = p.tx16; f.ty16 = p.ty16;
             f.tiles_x = (fh.tiles + p.tx16 - 1) / p.tx16; f.tiles_y = (fv.tiles + p.ty16 - 1) / p.ty16;
             f.pitch_c = p.pitch_c; f.pitch_r = p.pitch_r; f.rows16 = p.rows16;
-            pt->fused.push_back(f);
-            pt->fused_max_tiles = std::max(pt->fused_max_tiles, f.tiles_x * f.tiles_y);
+            const int n_tiles = f.tiles_x * f.tiles_y;
+            for (f.tile0 = 0; f.tile0 < n_tiles; f.tile0 += kRsTilesPerEntry) pt->fused.push_back(f);
+            pt->fused_max_tiles = std::max(pt->fused_max_tiles, std::min(n_tiles, kRsTilesPerEntry));
             pt->fused_lds = std::max(pt->fused_lds, rs_mfma_lds_bytes(f.rows16, f.pitch_c, f.tx16, f.pitch_r));
             continue;
         }
@@ -940,13 +940,13 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
     PassTables pt;
     std::vector<ResizePlan> plans{rp};
     if (int rc = plan_passes(ctx, plans, filter, ctx->arena, &pt)) return rc;
-    const size_t off_v = 64, off_f = 128, total = 128 + sizeof(RsMfma);
+    const size_t off_v = 64, off_f = 128, total = 128 + sizeof(RsMfma) * std::max<size_t>(1, pt.fused.size());
     Slot *slot = nullptr;
     if (int rc = acquire_slot(ctx, total, &slot)) return rc;
     char *hp = static_cast<char *>(slot->host);
     if (!pt.h.empty()) memcpy(hp, pt.h.data(), sizeof(RsJob));
     if (!pt.v.empty()) memcpy(hp + off_v, pt.v.data(), sizeof(RsJob));
-    if (!pt.fused.empty()) memcpy(hp + off_f, pt.fused.data(), sizeof(RsMfma));
+    if (!pt.fused.empty()) memcpy(hp + off_f, pt.fused.data(), sizeof(RsMfma) * pt.fused.size());
     HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, total, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(slot->ev, stream));
     slot->pending = true;

@@ -83,7 +83,7 @@ struct alignas(16) RsMfma {
     int32_t tiles_x, tiles_y;
     int32_t pitch_c, pitch_r;      // bytes per row of a source plane / per column of an intermediate plane
     int32_t rows16;                // rows of a source plane (multiple of 16)
-    int32_t pad;
+    int32_t tile0;                 // first workgroup tile of this table entry
 };
 static_assert(sizeof(RsMfma) == 112, "RsMfma layout");
 inline size_t rs_mfma_lds_bytes(int rows16, int pitch_c, int tx16, int pitch_r) {
@@ -91,6 +91,9 @@ inline size_t rs_mfma_lds_bytes(int rows16, int pitch_c, int tx16, int pitch_r) 
 }
 constexpr size_t kRsMfmaPreferredLds = 52 * 1024;  // three workgroups per CU (160 KB of LDS, 1 KB static each)
 constexpr size_t kRsMfmaMaxLds = 150 * 1024;       // last resort before the two-pass fallback
+// The launch is a (tiles per entry) x (entries) grid: a layer with more tiles takes several entries,
+// so that small layers do not pad the grid out to the largest layer's tile count.
+constexpr int kRsTilesPerEntry = 32;
 
 // ---- launchers (defined next to their kernels) -----------------------------------------------
 // The job table is sorted by kernel class; class_end[c] = one past the last job of class c for

@@ -72,3 +72,36 @@ def test_unpremultiply_reciprocal_table_exhaustive():
         assert R < 2 ** 32
         q = ((c << np.uint64(8)) * np.uint64(R)) >> np.uint64(32)
         assert np.array_equal(q, (255 * c) // a), a
+
+
+def test_unpremultiply_float_factor_exhaustive():
+    """kernels_resample.hip (MFMA kernel): min(255, 255*c // a) == min(255, floor(float32(c) * F[a]))
+    with F[a] = float32(255 / a) bumped up one ulp, for 0 < a < 255 and every byte c."""
+    c = np.arange(256)
+    for a in range(1, 255):
+        F = np.nextafter(np.float32(255.0) / np.float32(a), np.float32(np.inf))
+        assert F.dtype == np.float32
+        q = np.floor(c.astype(np.float32) * F).astype(np.int64)
+        assert np.array_equal(np.minimum(255, q), np.minimum(255, (255 * c) // a)), a
+
+
+def test_premultiply_packed_lanes_and_digit_split():
+    """kernels_resample.hip premultiply2_hi: two channels in 16-bit lanes of one register give
+    Pillow's MULDIV255 per lane (result in the lane's high byte); {G, 255} * a keeps alpha; and
+    resample_coeffs.cpp's signed-byte digits rebuild every 22-bit tap."""
+    a = np.arange(256, dtype=np.uint64)[:, None]
+    c = np.arange(256, dtype=np.uint64)[None, :]
+    x = c | (np.uint64(255) << np.uint64(16))               # lanes {c, 255}
+    t = (x * a + np.uint64(0x00800080)) & np.uint64(0xFFFFFFFF)
+    u = (t + ((t >> np.uint64(8)) & np.uint64(0x00FF00FF))) & np.uint64(0xFFFFFFFF)
+    lo, hi = (u >> np.uint64(8)) & np.uint64(255), (u >> np.uint64(24)) & np.uint64(255)
+    tt = c * a + np.uint64(128)
+    assert np.array_equal(lo, ((tt >> np.uint64(8)) + tt) >> np.uint64(8))  # Convert.c MULDIV255
+    assert np.array_equal(hi, np.broadcast_to(a, hi.shape))                   # alpha survives
+    k = np.arange(-(5 << 20), (5 << 20) + 1, 97, dtype=np.int64)  # taps are normalised: |k| <= ~2^22
+    d0 = ((k + 128) & 255) - 128
+    k1 = (k - d0) >> 8
+    d1 = ((k1 + 128) & 255) - 128
+    d2 = (k1 - d1) >> 8
+    assert np.array_equal(d0 + 256 * d1 + 65536 * d2, k)
+    assert d2.min() >= -128 and d2.max() <= 127
