@@ -115,6 +115,38 @@ def test_resize_golden_cases(gpu, golden_dir):
             assert np.array_equal(got, arrays[key]), (key, _maxdiff(got, arrays[key]))
 
 
+def test_resize_random_shapes_vs_oracle(gpu):
+    """The matrix-core resample kernel against the (golden-pinned) oracle on shapes that reach its
+    corners: many tiles per layer, windows cut by the right edge (width % 4 != 0), windows wider than
+    one 64-sample chunk (shrinks below 1/3), the LDS-heavy tiles, one-axis resizes (identity table on
+    the other axis), binary alpha (select path), tiny sources, and the two-pass fallback (extreme
+    shrink)."""
+    import ctypes
+    import torch
+    from image_transformation_amd import _native
+    lib = _native.lib()
+    rng = np.random.default_rng(77)
+    shapes = [((301, 203), (457, 311)), ((457, 311), (301, 203)), ((643, 97), (211, 97)), ((97, 643), (97, 211)),
+              ((1000, 800), (256, 205)), ((513, 259), (1026, 518)), ((130, 70), (1301, 707)), ((66, 66), (67, 65)),
+              ((799, 601), (160, 121)), ((1201, 5), (300, 5)), ((3, 900), (3, 100)), ((2, 2), (97, 33)),
+              ((1, 7), (50, 3)), ((4000, 16), (40, 16)), ((16, 4000), (17, 33)), ((257, 255), (255, 257)),
+              ((19, 23), (640, 480)), ((1023, 767), (511, 383))]
+    for i, ((sw, sh), (dw, dh)) in enumerate(shapes):
+        src = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
+        if i % 3 == 1:    # binary alpha, like the reference's bundles
+            src[:, :, 3] = np.where(rng.random((sh, sw)) < 0.45, 0, 255)
+        elif i % 3 == 2:  # mostly opaque with soft edges
+            src[:, :, 3] = np.where(rng.random((sh, sw)) < 0.8, 255, src[:, :, 3])
+        dev = torch.from_numpy(src).to(gpu.torch_device)
+        for filt in (_native.LANCZOS, _native.BILINEAR):
+            dst = torch.empty((dh, dw, 4), dtype=torch.uint8, device=gpu.torch_device)
+            _native.check(lib.mic_resize(gpu.handle, ctypes.c_void_p(dev.data_ptr()), sw, sh,
+                                         ctypes.c_void_p(dst.data_ptr()), dw, dh, filt, ctypes.c_void_p(gpu.stream_ptr())))
+            want = oracle.resize(src, (dw, dh), filt)
+            got = dst.cpu().numpy()
+            assert np.array_equal(got, want), ((sw, sh), (dw, dh), filt, _maxdiff(got, want))
+
+
 # ------------------------------------------------------------------------------------------ median / fill_solid
 def test_median_cases(gpu, golden_dir):
     from image_transformation_amd.background_resizing import _median_color_nontransparent
