@@ -83,6 +83,8 @@ SYMBOLS = {
     "mic_fill_solid": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8), _P]),
     "mic_fill_gradient": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8),
                                          ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, _P]),
+    "mic_draw_rect_outlines": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _I32P,
+                                              ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, _P]),
     "mic_flex_place": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, _I32P, _I32P, _I32P,
                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _I32P, _I32P, _I32P]),
     "mic_thumbnail_size": (ctypes.c_int, [ctypes.c_int32] * 4 + [_I32P, _I32P]),

@@ -1007,6 +1007,46 @@ extern "C" int mic_fill_gradient(mic_ctx *ctx, void *out_dev, int32_t width, int
     return MIC_OK;
 }
 
+extern "C" int mic_draw_rect_outlines(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height, int32_t n,
+                                      const int32_t *boxes, const uint8_t *colours, int32_t outline_width,
+                                      void *stream_v) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (!out_dev || width <= 0 || height <= 0 || width > kMaxDim || height > kMaxDim || n < 0 ||
+        (n > 0 && (!boxes || !colours)) || outline_width < 0 || outline_width > kMaxDim)
+        return fail(MIC_ERR_INVALID, "mic_draw_rect_outlines: bad arguments");
+    if (int rc = adopt_stream(ctx, stream)) return rc;
+    const int w = outline_width == 0 ? 1 : outline_width;  // Draw.c: width 0 draws width 1
+    std::vector<OutlineRect> rects((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int64_t x0 = boxes[4 * i], y0 = boxes[4 * i + 1], x1 = boxes[4 * i + 2], y1 = boxes[4 * i + 3];
+        if (x1 < x0 || y1 < y0)
+            return fail(MIC_ERR_INVALID, "box %d: %s must be greater than or equal to %s", i, x1 < x0 ? "x1" : "y1",
+                        x1 < x0 ? "x0" : "y0");
+        auto clampi = [](int64_t v) { return (int32_t)std::max<int64_t>(-(1 << 30), std::min<int64_t>(v, 1 << 30)); };
+        // the vertical lines start at ya and take |yb - ya| steps towards yb without reaching it
+        const int64_t ya = y0 + w, yb = y1 - w + 1;
+        const int64_t vlo = yb > ya ? ya : yb + 1, vhi = yb > ya ? yb - 1 : ya;
+        OutlineRect r{};
+        r.x0 = clampi(x0); r.y0 = clampi(y0); r.x1 = clampi(x1); r.y1 = clampi(y1);
+        r.vlo = clampi(vlo); r.vhi = clampi(vhi);
+        r.ymin = clampi(std::min(std::min(y0, y1 - w + 1), vlo));
+        r.ymax = clampi(std::max(std::max(y1, y0 + w - 1), vhi));
+        r.rgba = (uint32_t)colours[4 * i] | ((uint32_t)colours[4 * i + 1] << 8) | ((uint32_t)colours[4 * i + 2] << 16) |
+                 ((uint32_t)colours[4 * i + 3] << 24);
+        rects[(size_t)i] = r;
+    }
+    const size_t bytes = std::max<size_t>(sizeof(OutlineRect), sizeof(OutlineRect) * rects.size());
+    Slot *slot = nullptr;
+    if (int rc = acquire_slot(ctx, bytes, &slot)) return rc;
+    if (n > 0) memcpy(slot->host, rects.data(), sizeof(OutlineRect) * rects.size());
+    HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(slot->ev, stream));
+    slot->pending = true;
+    HIP_TRY(launch_rect_outlines(out_dev, width, height, static_cast<const OutlineRect *>(slot->dev), n, w, stream));
+    return MIC_OK;
+}
+
 extern "C" int mic_flex_place(const char *layout_json, size_t len, int n_objects, const int32_t *ids,
                               const int32_t *widths, const int32_t *heights, int32_t canvas_w, int32_t canvas_h,
                               int32_t capacity, int32_t *out_ids, int32_t *out_boxes, int32_t *out_count) {

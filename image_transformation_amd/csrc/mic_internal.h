@@ -110,6 +110,17 @@ hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int max_tile
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);
 hipError_t launch_gradient(void *out, int W, int H, const uint8_t c1[3], const uint8_t c2[3], int vertical,
                            hipStream_t stream);
+// One rectangle outline of the debug overlay (kernels_overlay.hip), resolved on the host.
+struct alignas(16) OutlineRect {
+    int32_t x0, y0, x1, y1;  // ImageDraw.rectangle's box, inclusive
+    int32_t vlo, vhi;        // rows covered by the two vertical lines (vlo > vhi: none)
+    int32_t ymin, ymax;      // rows the whole outline can touch
+    uint32_t rgba;
+    int32_t pad[3];
+};
+static_assert(sizeof(OutlineRect) == 48, "OutlineRect layout");
+hipError_t launch_rect_outlines(void *out, int W, int H, const OutlineRect *rects_dev, int n, int width,
+                                hipStream_t stream);
 // hist: uint32 [2][3][256] + counts[2] + ticket; must be zero on entry, the kernel leaves it zeroed.
 hipError_t launch_median(const void *rgba, size_t n_px, uint32_t *hist_dev, uint32_t *out_rgba_dev,
                          hipStream_t stream);

@@ -26,6 +26,7 @@ from .compositor import SolidCanvas, coerce_placements, composite_device, load_o
 from .contact_sheet import build_labeled_contact_sheet
 from .flex import layout_to_placements
 from .layout_constraints import compute_canvas_size
+from .overlay import save_overlay_debug
 
 
 def read_original_size(bundle_dir: Path) -> Tuple[int, int]:
@@ -103,6 +104,8 @@ def run_layouts(bundle_dir: str, ratio: str, flex_layouts: Sequence[Dict[str, An
             (d["layout_json"] / f"layout_macro_iter_{i:02d}.json").write_text(json.dumps(final_json, indent=2),
                                                                               encoding="utf-8")
             draft.save(d["final_product"] / f"draft_macro_iter_{i:02d}.png")
+            save_overlay_debug(final_json["placements"], canvas_size,
+                               d["final_product"] / f"overlay_debug_iter_{i:02d}.png")  # :1514, :1700
             (d["layout_json"] / f"provenance_iter_{i:02d}.json").write_text(
                 json.dumps({"method": "flex", "fallback": False, "iteration": i}, indent=2), encoding="utf-8")
     return {"canvas_size": canvas_size, "background_rgba": canvas.rgba, "contact_sheet": sheet, "drafts": drafts,

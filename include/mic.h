@@ -149,6 +149,15 @@ int mic_fill_solid(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height,
 int mic_fill_gradient(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height, const uint8_t c1[3],
                       const uint8_t c2[3], int vertical, void *stream);
 
+/* _save_overlay_debug's drawing (macro_placement_test.py:967-983): a transparent RGBA image of
+ * width x height on which ImageDraw.rectangle(box, outline=colour, width=outline_width) is applied
+ * per box, in order (later outlines overwrite earlier ones; nothing is blended).
+ * boxes_xyxy: n x 4 int32 (x1, y1, x2, y2 as in a placement's "box", inclusive corners, x2 >= x1 and
+ * y2 >= y1 or MIC_ERR_INVALID -- ImageDraw raises ValueError there); colours_rgba: n x 4 bytes.    */
+int mic_draw_rect_outlines(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height, int32_t n,
+                           const int32_t *boxes_xyxy, const uint8_t *colours_rgba, int32_t outline_width,
+                           void *stream);
+
 /* ---- layout: the integer half of render() -------------------------------------------------
  * Flex-DSL JSON text ({"root": {...}}) + cutout sizes + canvas size -> object ids and clamped boxes
  * in depth-first order: _measure_flex_node / _place_flex_container / _clamp_boxes_to_canvas

@@ -58,6 +58,8 @@ def lib() -> ctypes.CDLL:
         L.orc_median_rgb.restype = None
         L.orc_fill_solid.argtypes = [u8p, ctypes.c_int, ctypes.c_int, u8p]
         L.orc_fill_solid.restype = None
+        L.orc_rect_outlines.argtypes = [u8p, ctypes.c_int, ctypes.c_int, ctypes.c_int, i32p, u8p, ctypes.c_int]
+        L.orc_rect_outlines.restype = None
         L.orc_thumbnail_size.argtypes = [ctypes.c_int] * 4 + [ctypes.POINTER(ctypes.c_int)] * 2
         L.orc_thumbnail_size.restype = None
         L.orc_resample_coeffs.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -182,6 +184,43 @@ def median_rgb(rgba: np.ndarray) -> Tuple[int, int, int]:
     out = np.zeros(3, np.uint8)
     lib().orc_median_rgb(_u8(a), a.shape[0] * a.shape[1], _u8(out))
     return int(out[0]), int(out[1]), int(out[2])
+
+
+OVERLAY_COLORS = [(255, 99, 71, 180), (135, 206, 235, 180), (60, 179, 113, 180), (238, 130, 238, 180),
+                  (255, 215, 0, 180), (30, 144, 255, 180)]  # macro_placement_test.py:971-978
+
+
+def rect_outlines(size: Tuple[int, int], boxes: Sequence[Sequence[int]], colors: Sequence[Sequence[int]],
+                  width: int = 3) -> np.ndarray:
+    """ImageDraw.rectangle(box, outline=colour, width=width) per box, in order, on a transparent
+    RGBA image of `size` (macro_placement_test.py:967-983)."""
+    w, h = int(size[0]), int(size[1])
+    out = np.empty((h, w, 4), np.uint8)
+    b = np.ascontiguousarray(np.asarray(boxes, np.int32).reshape(-1, 4))
+    c = np.ascontiguousarray(np.asarray(colors, np.uint8).reshape(-1, 4))
+    assert len(b) == len(c)
+    lib().orc_rect_outlines(_u8(out), w, h, len(b), _i32(b), _u8(c), int(width))
+    return out
+
+
+def overlay_debug(placements: Sequence[dict], canvas_size: Tuple[int, int]) -> np.ndarray:
+    """_save_overlay_debug's image (before the PNG encoder)."""
+    boxes = [[int(v) for v in p["box"]] for p in placements]
+    colors = [OVERLAY_COLORS[i % len(OVERLAY_COLORS)] for i in range(len(boxes))]
+    if not boxes:
+        return np.zeros((int(canvas_size[1]), int(canvas_size[0]), 4), np.uint8)
+    return rect_outlines(canvas_size, boxes, colors, 3)
+
+
+def candidates_grid(images: Sequence[np.ndarray]) -> np.ndarray:
+    """_compose_candidates_grid (macro_placement_test.py:1332-1345): every image resized (LANCZOS) to
+    the first one's size, alpha-composited onto a white 2x2 grid; more than four are ignored (zip)."""
+    ref_h, ref_w = images[0].shape[:2]
+    bg = np.full((2 * ref_h, 2 * ref_w, 4), 255, np.uint8)
+    pos = [(0, 0), (ref_w, 0), (0, ref_h), (ref_w, ref_h)]
+    objs = {i + 1: im for i, im in enumerate(images[:4])}
+    pl = [{"object_id": i + 1, "box": [x, y, x + ref_w, y + ref_h]} for i, (x, y) in enumerate(pos[:len(objs)])]
+    return composite(bg, objs, pl)
 
 
 def fill_solid(size: Tuple[int, int], rgba: Sequence[int]) -> np.ndarray:

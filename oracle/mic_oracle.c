@@ -316,3 +316,38 @@ void orc_thumbnail_size(int w, int h, int req_w, int req_h, int *out_w, int *out
     *out_w = x;
     *out_h = y;
 }
+
+/* macro_placement_test.py:967-983 _save_overlay_debug: a transparent RGBA overlay on which
+ * ImageDraw.rectangle([x1, y1, x2, y2], outline=colour, width=3) is called per placement, in order
+ * (ImageDraw on an RGBA image stores the ink, it does not blend: later outlines overwrite).
+ * Restates Pillow Draw.c ImagingDrawRectangle's outline branch as the installed Pillow behaves
+ * (probed in the build container, pinned by tests/golden/overlay.npz): per i < width two clipped
+ * horizontal lines at y0 + i and y1 - i over x0..x1, and two vertical lines at x1 - i and x0 + i that
+ * start at y0 + width and run |dy| pixels TOWARDS y1 - width + 1 without reaching it -- for boxes
+ * thinner than 2 width the "towards" is upwards and the outline spills outside the box.
+ * Callers guarantee x1 >= x0 and y1 >= y0 (ImageDraw raises ValueError otherwise).
+ */
+static void orc_put(uint8_t *out, int W, int H, int x, int y, const uint8_t *ink) {
+    if (x >= 0 && x < W && y >= 0 && y < H) memcpy(out + ((size_t)y * W + x) * 4, ink, 4);
+}
+
+void orc_rect_outlines(uint8_t *out, int W, int H, int n, const int32_t *boxes, const uint8_t *rgba, int width) {
+    memset(out, 0, (size_t)W * H * 4);
+    if (width <= 0) width = 1;
+    for (int r = 0; r < n; ++r) {
+        const int x0 = boxes[4 * r], y0 = boxes[4 * r + 1], x1 = boxes[4 * r + 2], y1 = boxes[4 * r + 3];
+        const uint8_t *ink = rgba + 4 * r;
+        for (int i = 0; i < width; ++i) {
+            for (int x = x0; x <= x1; ++x) {
+                orc_put(out, W, H, x, y0 + i, ink);
+                orc_put(out, W, H, x, y1 - i, ink);
+            }
+            const int ya = y0 + width, yb = y1 - width + 1;
+            const int dy = yb > ya ? yb - ya : ya - yb, ys = yb > ya ? 1 : -1;
+            for (int k = 0, y = ya; k < dy; ++k, y += ys) {
+                orc_put(out, W, H, x1 - i, y, ink);
+                orc_put(out, W, H, x0 + i, y, ink);
+            }
+        }
+    }
+}

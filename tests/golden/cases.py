@@ -170,6 +170,57 @@ def median_case(idx: int) -> dict:
 N_MEDIAN = 24
 
 
+# ----------------------------------------------------------------------------- overlay rectangles / candidates grid
+def overlay_case(idx: int) -> dict:
+    """Placement boxes for _save_overlay_debug (macro_placement_test.py:967-983): ordinary boxes,
+    boxes thinner than twice the outline width (Pillow's outline then spills outside the box),
+    boxes overhanging every canvas edge, and heavy overlap (later outlines overwrite earlier ones)."""
+    rng = np.random.default_rng(70_000 + idx)
+    W, H = [(97, 61), (160, 120), (33, 200), (256, 40), (64, 64), (1, 1), (7, 5), (300, 200)][idx % 8]
+    n = int(rng.integers(1, 14))
+    pl = []
+    for k in range(n):
+        kind = int(rng.integers(0, 4))
+        if kind == 0:    # ordinary
+            w, h = int(rng.integers(7, max(8, W // 2 + 8))), int(rng.integers(7, max(8, H // 2 + 8)))
+        elif kind == 1:  # thin: 0..6 px on one or both sides
+            w, h = int(rng.integers(0, 7)), int(rng.integers(0, 30))
+            if rng.random() < 0.5:
+                w, h = h, w
+        elif kind == 2:  # bigger than the canvas
+            w, h = int(rng.integers(W, 2 * W + 3)), int(rng.integers(1, H + 10))
+        else:
+            w, h = int(rng.integers(1, 12)), int(rng.integers(1, 12))
+        x1, y1 = int(rng.integers(-12, W + 6)), int(rng.integers(-12, H + 6))
+        pl.append({"object_id": k + 1, "box": [x1, y1, x1 + w, y1 + h]})
+    return dict(name=f"overlay_{idx}_{W}x{H}", canvas=(W, H), placements=pl)
+
+
+N_OVERLAY = 24
+
+
+def grid_case(idx: int) -> dict:
+    """Up to four RGBA candidate images of different sizes for _compose_candidates_grid
+    (macro_placement_test.py:1332-1345): the first one sets the cell size."""
+    rng = np.random.default_rng(80_000 + idx)
+    n = [4, 3, 1, 2, 4][idx % 5]
+    ref_w, ref_h = int(rng.integers(20, 90)), int(rng.integers(20, 70))
+    imgs = []
+    for k in range(n):
+        if k == 0 or rng.random() < 0.3:
+            w, h = ref_w, ref_h
+        else:
+            w, h = int(rng.integers(8, 140)), int(rng.integers(8, 120))
+        a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        if rng.random() < 0.5:
+            a[:, :, 3] = np.where(rng.random((h, w)) < 0.4, 0, 255)
+        imgs.append(a)
+    return dict(name=f"grid_{idx}", images=imgs)
+
+
+N_GRID = 5
+
+
 # ----------------------------------------------------------------------------- flex trees
 JUSTIFY = ["start", "center", "end", "space_between", "space_around"]
 ALIGN = ["start", "center", "end"]

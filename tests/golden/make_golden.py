@@ -359,12 +359,45 @@ def gen_gradient():
     dump_json("gradient.json", {"meta": META, "cases": rows})
 
 
+def gen_overlay():
+    """_save_overlay_debug (macro_placement_test.py:967-983) and _compose_candidates_grid (:1332-1345):
+    both write PNGs; the fixtures keep the decoded pixels."""
+    import tempfile
+    from pathlib import Path
+    rows, arrays = [], {}
+    with tempfile.TemporaryDirectory() as td:
+        for i in range(cases.N_OVERLAY):
+            c = cases.overlay_case(i)
+            pth = Path(td) / f"{c['name']}.png"
+            ref_mp._save_overlay_debug(c["placements"], tuple(c["canvas"]), pth)
+            out = to_arr(Image.open(pth).convert("RGBA"))
+            arrays[c["name"]] = out
+            rows.append({"name": c["name"], "canvas": list(c["canvas"]), "placements": c["placements"],
+                         "sha16": cases.sha16(out)})
+        for i in range(cases.N_GRID):
+            c = cases.grid_case(i)
+            paths = []
+            for k, a in enumerate(c["images"]):
+                pth = Path(td) / f"{c['name']}_{k}.png"
+                to_img(a).save(pth)
+                paths.append(pth)
+            paths.insert(1, Path(td) / "missing.png")  # non-existent paths are skipped (:1333)
+            outp = Path(td) / f"{c['name']}_grid.png"
+            ref_mp._compose_candidates_grid(paths, outp)
+            out = to_arr(Image.open(outp).convert("RGBA"))
+            arrays[c["name"]] = out
+            rows.append({"name": c["name"], "n": len(c["images"]), "size": [out.shape[1], out.shape[0]],
+                         "sha16": cases.sha16(out)})
+    np.savez_compressed(os.path.join(HERE, "overlay.npz"), **arrays)
+    dump_json("overlay.json", {"meta": META, "cases": rows})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["bundles_copy", "canvas", "flex", "composite", "resize", "median", "bundles",
-                             "contact", "big", "gradient"]
+                             "contact", "big", "gradient", "overlay"]
     steps = {"bundles_copy": copy_bundles, "canvas": gen_canvas_sizes, "flex": gen_flex,
              "composite": gen_composite, "resize": gen_resize, "median": gen_median, "bundles": gen_bundles,
-             "contact": gen_contact_sheets, "big": gen_big_hashes, "gradient": gen_gradient}
+             "contact": gen_contact_sheets, "big": gen_big_hashes, "gradient": gen_gradient, "overlay": gen_overlay}
     for w in which:
         print("==", w, flush=True)
         steps[w]()

@@ -183,3 +183,36 @@ def test_run_layouts_harness_matches_reference_goldens(golden_dir, tmp_path):
     assert os.path.exists(os.path.join(out, "iteration_00", "vlm_input_image", "contact_sheet.png"))
     canvas_png = np.array(Image.open(os.path.join(out, "iteration_00", "vlm_input_image", "canvas.png")).convert("RGBA"))
     assert canvas_png.shape == (492, 492, 4) and (canvas_png == np.array([220, 238, 245, 255], np.uint8)).all()
+    for i in range(3):  # overlay_debug_iter_XX.png (macro_placement_test.py:1514, :1700) == the oracle's drawing
+        ov = np.array(Image.open(os.path.join(out, f"iteration_{i:02d}", "final_product",
+                                              f"overlay_debug_iter_{i:02d}.png")).convert("RGBA"))
+        assert np.array_equal(ov, oracle.overlay_debug(res["placements"][i], (492, 492)))
+        assert ov[:, :, 3].max() == 180 and ov[0, 0, 3] == 0
+
+
+@pytest.mark.gpu
+def test_overlay_rectangles_and_candidates_grid_gpu(golden_dir):
+    """SURVEY section 8f row 4 on the device: mic_draw_rect_outlines and the composite-built 2x2 grid
+    against the pixels the reference's _save_overlay_debug / _compose_candidates_grid produced."""
+    from PIL import Image
+    from image_transformation_amd import overlay
+    arrays = np.load(os.path.join(golden_dir, "overlay.npz"))
+    for i in range(cases.N_OVERLAY):
+        c = cases.overlay_case(i)
+        got = np.array(overlay.overlay_debug(c["placements"], c["canvas"]))
+        assert np.array_equal(got, arrays[c["name"]]), c["name"]
+    for i in range(cases.N_GRID):
+        c = cases.grid_case(i)
+        got = overlay.candidates_grid_device([Image.fromarray(a, "RGBA") for a in c["images"]]).cpu().numpy()
+        assert np.array_equal(got, arrays[c["name"]]), c["name"]
+    # full-size: 4K canvas, 150 outlines, against the oracle; then ImageDraw's own argument check
+    rng = np.random.default_rng(5)
+    pl = []
+    for k in range(150):
+        x1, y1 = int(rng.integers(-50, 3800)), int(rng.integers(-50, 2100))
+        pl.append({"object_id": k, "box": [x1, y1, x1 + int(rng.integers(0, 900)), y1 + int(rng.integers(0, 700))]})
+    got = overlay.overlay_debug_device(pl, (3840, 2160)).cpu().numpy()
+    assert np.array_equal(got, oracle.overlay_debug(pl, (3840, 2160)))
+    with pytest.raises(ValueError, match="x1 must be greater than or equal to x0"):
+        overlay.overlay_debug([{"object_id": 1, "box": [5, 5, 3, 8]}], (10, 10))
+    assert not np.array(overlay.overlay_debug([], (7, 3))).any()

@@ -148,3 +148,23 @@ def test_thumbnails_and_size_rule(golden_dir):
         for t in row["thumbs"]:
             th = oracle.thumbnail(objs[t["object_id"]])
             assert np.array_equal(th, arrays[f"{row['bundle']}_thumb_{t['object_id']}"])
+
+
+def test_overlay_rectangles_and_candidates_grid(golden_dir):
+    """_save_overlay_debug and _compose_candidates_grid of the reference
+    (macro_placement_test.py:967-983, 1332-1345), pixels captured by make_golden.py."""
+    with open(os.path.join(golden_dir, "overlay.json"), encoding="utf-8") as f:
+        meta = json.load(f)
+    arrays = np.load(os.path.join(golden_dir, "overlay.npz"))
+    seen = 0
+    for i in range(cases.N_OVERLAY):
+        c = cases.overlay_case(i)
+        got = oracle.overlay_debug(c["placements"], c["canvas"])
+        assert np.array_equal(got, arrays[c["name"]]), c["name"]
+        seen += 1
+    for i in range(cases.N_GRID):
+        c = cases.grid_case(i)
+        got = oracle.candidates_grid(c["images"])
+        assert np.array_equal(got, arrays[c["name"]]), c["name"]
+        seen += 1
+    assert seen == len(meta["cases"])
