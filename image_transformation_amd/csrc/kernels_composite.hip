@@ -60,14 +60,18 @@ __device__ __forceinline__ uint32_t alpha_over(uint32_t d, uint32_t s) {
 // it reduces EXACTLY to out.c = div255(s.c*sa + d.c*(255-sa) + 128), out.a = 255 (checked for all
 // 2^24 (sa, s.c, d.c) triples, tests/test_blend_identities.py).  R and B ride in the two 16-bit
 // halves of one register (255*255 + 128 < 2^16, so the halves never carry into each other).
+// {G, 255} ride in a second register the same way: 255*sa + 255*(255-sa) + 128 divides to 255, the
+// output alpha.  Each div255 leaves its result in bytes 1 and 3 of t + {t.b1, 0, t.b3, 0}, and one
+// v_perm_b32 gathers the four result bytes: 15 instructions per pixel (the scalar form took 23).
 __device__ __forceinline__ uint32_t over_opaque_dst(uint32_t d, uint32_t s) {
     const uint32_t sa = s >> 24, na = 255u - sa;
     const uint32_t M = 0x00FF00FFu;
-    uint32_t rb = (s & M) * sa + (d & M) * na + 0x00800080u;
-    uint32_t g = ((s >> 8) & 0xFFu) * sa + ((d >> 8) & 0xFFu) * na + 0x80u;
-    rb = ((((rb >> 8) & M) + rb) >> 8) & M;
-    g = ((g >> 8) + g) >> 8;
-    return rb | (g << 8) | 0xFF000000u;
+    const uint32_t s_ga = __builtin_amdgcn_perm(s, s, 0x0c0d0c01u), d_ga = __builtin_amdgcn_perm(d, d, 0x0c0d0c01u);
+    uint32_t rb = __umul24(d & M, na) + (__umul24(s & M, sa) + 0x00800080u);
+    uint32_t ga = __umul24(d_ga, na) + (__umul24(s_ga, sa) + 0x00800080u);
+    rb += __builtin_amdgcn_perm(rb, rb, 0x0c030c01u);  // + ((rb >> 8) & M): results in bytes 1, 3
+    ga += __builtin_amdgcn_perm(ga, ga, 0x0c030c01u);
+    return __builtin_amdgcn_perm(ga, rb, 0x07030501u);  // {rb.b1, ga.b1, rb.b3, ga.b3} = R, G, B, 255
 }
 
 // Canvas traffic is touched once: nontemporal hints (background reads, canvas stores).
@@ -150,12 +154,14 @@ __device__ __forceinline__ u32x4 load_tap(const Layer &L, const Tap &t) {
 #endif
 }
 
-// Keep the loaded pixels j in [jlo, jhi) that lie inside the layer row, zero (transparent) the rest.
-__device__ __forceinline__ u32x4 mask_tap(const Tap &t, const Layer &L, u32x4 v, int jlo, int jhi) {
+// Keep the loaded pixels whose layer column c = t.sx + j satisfies lo <= c < lo + span, zero
+// (transparent) the rest.  For the pixels of a group that lie in the group's own row, lo = 0 and
+// span = the layer's width clipped at the canvas' right edge: that one bound also drops the pixels
+// of a row-straddling group (W % 4 != 0) that belong to the next row, since their columns are >= W.
+__device__ __forceinline__ u32x4 mask_tap(const Tap &t, u32x4 v, int lo, int span) {
     u32x4 s;
 #pragma unroll
-    for (int j = 0; j < kLaneNPx; ++j)
-        s[j] = ((uint32_t)(t.sx + j) < (uint32_t)L.w && j >= jlo && j < jhi) ? v[j] : 0u;
+    for (int j = 0; j < kLaneNPx; ++j) s[j] = (uint32_t)(t.sx + j - lo) < (uint32_t)span ? v[j] : 0u;
     return s;
 }
 
@@ -273,6 +279,15 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
         dst_opaque = !__any(amin < 0xFF000000u);
     }
 
+    // W % 4 != 0: which of this lane's groups run over a row end (pixels W - x .. 3 continue at column 0
+    // of the next row), and whether any lane of the wave has one -- once per page, not per round.
+    bool strad[kGroups], any_strad[kGroups];
+#pragma unroll
+    for (int r = 0; r < kGroups; ++r) {
+        strad[r] = !ALIGNED && G[r].k < kLaneNPx;
+        any_strad[r] = !ALIGNED && __any(strad[r]);
+    }
+
     // ---- layers ----
     // Order only matters among layers that touch the same pixels, so each of the four groups walks
     // ITS OWN hit mask in list order: one round issues up to four independent 16-byte loads per lane
@@ -319,16 +334,18 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
             }
 #pragma unroll
             for (int r = 0; r < kGroups; ++r) {  // consume
-                s[r] = mask_tap(tap[r], L[r], s[r], 0, ALIGNED ? kLaneNPx : G[r].k);
-                if (!ALIGNED) {
-                    // a group that straddles a row end: its pixels k..3 continue at column 0 of the
-                    // next row -- one more masked 16-byte load, only in waves that hold such a group
-                    if (__any(G[r].k < kLaneNPx)) {
-                        const Tap t2 = make_tap(L[r], G[r].x - W, G[r].y + 1, has_layer[r] && G[r].k < kLaneNPx);
-                        const u32x4 v2 = mask_tap(t2, L[r], load_tap(L[r], t2), G[r].k, kLaneNPx);
+                // the layer clipped at the canvas' right edge (only matters when groups can straddle)
+                const int wclip = ALIGNED ? L[r].w : min(L[r].w, W - L[r].dx);
+                s[r] = mask_tap(tap[r], s[r], 0, wclip);
+                if (!ALIGNED && any_strad[r]) {
+                    // a group that straddles a row end: its pixels W - x .. 3 continue at column 0 of
+                    // the next row -- one more masked 16-byte load, only in waves that hold such a
+                    // group.  Canvas column = x - W + j >= 0 <=> layer column >= -dx: clip on the left.
+                    const Tap t2 = make_tap(L[r], G[r].x - W, G[r].y + 1, has_layer[r] && strad[r]);
+                    const int lo = max(0, -L[r].dx);
+                    const u32x4 v2 = mask_tap(t2, load_tap(L[r], t2), lo, wclip - lo);
 #pragma unroll
-                        for (int j = 0; j < kLaneNPx; ++j) s[r][j] |= v2[j];
-                    }
+                    for (int j = 0; j < kLaneNPx; ++j) s[r][j] |= v2[j];
                 }
             }
             // partial alpha anywhere in the wave?  (sa + 1) & 0xFE == 0  <=>  sa in {0, 255}
