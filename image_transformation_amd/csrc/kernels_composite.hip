@@ -281,12 +281,10 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
 
     // W % 4 != 0: which of this lane's groups run over a row end (pixels W - x .. 3 continue at column 0
     // of the next row), and whether any lane of the wave has one -- once per page, not per round.
-    bool strad[kGroups], any_strad[kGroups];
+    uint32_t strad_mask = 0;  // bit r: some lane's group r straddles (kept as one scalar: SGPRs are scarce here)
 #pragma unroll
-    for (int r = 0; r < kGroups; ++r) {
-        strad[r] = !ALIGNED && G[r].k < kLaneNPx;
-        any_strad[r] = !ALIGNED && __any(strad[r]);
-    }
+    for (int r = 0; r < kGroups; ++r)
+        if (!ALIGNED && __any(G[r].k < kLaneNPx)) strad_mask |= 1u << r;
 
     // ---- layers ----
     // Order only matters among layers that touch the same pixels, so each of the four groups walks
@@ -297,11 +295,33 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
         // cull 64 layers at once: lane l holds record base + l
         Layer mine{};
         bool hit[kGroups] = {false, false, false, false};
+        // The runs' end points are recomputed here from the page origin (a few scalar adds) rather
+        // than kept in 16 SGPRs across the rounds below: the unaligned instantiations were spilling
+        // scalars.  The empty asm makes the origin opaque so that the recomputation is not hoisted.
+        uint32_t ox = x0;
+        int oy = y0;
+        asm volatile("" : "+s"(ox), "+s"(oy));
         if (base + lane < job.layer_count) {
             mine = jl[base + lane];
 #pragma unroll
-            for (int r = 0; r < kGroups; ++r)
-                hit[r] = run_hits(ra[r], ca[r], rb[r], cb[r], W, mine.dx, mine.dy, mine.w, mine.h);
+            for (int r = 0; r < kGroups; ++r) {
+                int a_r, a_c, b_r, b_c;
+                if (W >= kPagePx) {
+                    uint32_t xf = ox + (uint32_t)(r * kWavePx);
+                    int yf = oy;
+                    if (xf >= uW) { xf -= uW; yf += 1; }
+                    uint32_t xl = xf + (uint32_t)(kWavePx - 1);
+                    int yl = yf;
+                    if (xl >= uW) { xl -= uW; yl += 1; }
+                    a_r = yf; a_c = (int)xf; b_r = yl; b_c = (int)xl;
+                } else {
+                    const uint32_t f = ox + (uint32_t)(r * kWavePx), l = f + (uint32_t)(kWavePx - 1);
+                    const uint32_t df = f / uW, dl = l / uW;
+                    a_r = oy + (int)df; a_c = (int)(f - df * uW);
+                    b_r = oy + (int)dl; b_c = (int)(l - dl * uW);
+                }
+                hit[r] = run_hits(a_r, a_c, b_r, b_c, W, mine.dx, mine.dy, mine.w, mine.h);
+            }
         }
         uint64_t m[kGroups];
 #pragma unroll
@@ -337,34 +357,43 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
                 // the layer clipped at the canvas' right edge (only matters when groups can straddle)
                 const int wclip = ALIGNED ? L[r].w : min(L[r].w, W - L[r].dx);
                 s[r] = mask_tap(tap[r], s[r], 0, wclip);
-                if (!ALIGNED && any_strad[r]) {
+                if (!ALIGNED && ((strad_mask >> r) & 1u)) {
                     // a group that straddles a row end: its pixels W - x .. 3 continue at column 0 of
                     // the next row -- one more masked 16-byte load, only in waves that hold such a
                     // group.  Canvas column = x - W + j >= 0 <=> layer column >= -dx: clip on the left.
-                    const Tap t2 = make_tap(L[r], G[r].x - W, G[r].y + 1, has_layer[r] && strad[r]);
+                    const Tap t2 = make_tap(L[r], G[r].x - W, G[r].y + 1, has_layer[r] && G[r].k < kLaneNPx);
                     const int lo = max(0, -L[r].dx);
                     const u32x4 v2 = mask_tap(t2, load_tap(L[r], t2), lo, wclip - lo);
 #pragma unroll
                     for (int j = 0; j < kLaneNPx; ++j) s[r][j] |= v2[j];
                 }
             }
-            // partial alpha anywhere in the wave?  (sa + 1) & 0xFE == 0  <=>  sa in {0, 255}
-            uint32_t soft = 0;
+            // Blend path per 256-pixel group (wave-uniform choices): a group without a layer this round
+            // is skipped; a group whose source pixels all have alpha 0 or 255 -- (sa + 1) & 0xFE == 0 --
+            // takes the select (what the formula gives, exactly, for any dst); partial alpha anywhere in
+            // the group sends it through the arithmetic.  Resampled binary cutouts are soft only along
+            // their edges, so most groups of a placements-mode canvas still take the select.
+            bool soft_g[kGroups], any_soft = false;
 #pragma unroll
-            for (int r = 0; r < kGroups; ++r)
+            for (int r = 0; r < kGroups; ++r) {
+                uint32_t soft = 0;
 #pragma unroll
                 for (int j = 0; j < kLaneNPx; ++j) soft |= ((s[r][j] >> 24) + 1u) & 0xFEu;
-            if (!__any(soft != 0)) {
-                // alpha 0 keeps dst, alpha 255 takes src: what the formula gives, exactly, for any dst
+                soft_g[r] = has_layer[r] && __any(soft != 0);
+                any_soft = any_soft || soft_g[r];
+            }
+            if (SOLID || dst_opaque || !any_soft) {
 #pragma unroll
-                for (int r = 0; r < kGroups; ++r)
+                for (int r = 0; r < kGroups; ++r) {
+                    if (!has_layer[r]) continue;
+                    if (soft_g[r]) {
 #pragma unroll
-                    for (int j = 0; j < kLaneNPx; ++j) px[r][j] = s[r][j] >= 0xFF000000u ? s[r][j] : px[r][j];
-            } else if (SOLID || dst_opaque) {
+                        for (int j = 0; j < kLaneNPx; ++j) px[r][j] = over_opaque_dst(px[r][j], s[r][j]);
+                    } else {
 #pragma unroll
-                for (int r = 0; r < kGroups; ++r)
-#pragma unroll
-                    for (int j = 0; j < kLaneNPx; ++j) px[r][j] = over_opaque_dst(px[r][j], s[r][j]);
+                        for (int j = 0; j < kLaneNPx; ++j) px[r][j] = s[r][j] >= 0xFF000000u ? s[r][j] : px[r][j];
+                    }
+                }
             } else if (!SOLID) {
                 // translucent destination (a background with alpha < 255): the verbatim formula, one
                 // pixel at a time through ONE copy of the code (registers rotate), so that this rare
