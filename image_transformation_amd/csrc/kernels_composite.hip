@@ -212,10 +212,15 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
 
     const int64_t qp = (int64_t)blockIdx.x * kPagePx - job.px_shift;
     // pages that lie wholly inside the canvas: all but the first/last of a page-misaligned canvas
-    if (qp < 0 || qp + kPagePx > n_px || W < kLaneNPx) {
+    if (qp < 0 || W < kLaneNPx) {
         edge_page(job, jl, qp, lane);
         return;
     }
+    // The last page of a canvas whose size is not a multiple of 4 KiB runs through the normal path
+    // with guarded canvas accesses: its pixels past the end lie in rows >= H, which no store reaches.
+    // (It used to take edge_page; being the last workgroup dispatched, that slow loop was the tail of
+    // the whole launch -- every canvas whose width is not a multiple of 4 has such a page.)
+    const bool tail = qp + kPagePx > n_px;  // wave-uniform
     const int64_t q_lane = qp + lane * kLaneNPx;  // group r starts at q_lane + r * 256
 
     // The four 256-pixel runs of the page as (row, column) of both ends, and this lane's four
@@ -271,7 +276,15 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
         gcptr bg = reinterpret_cast<gcptr>(job.bg) + q_lane;
         uint32_t amin = 0xFFFFFFFFu;
 #pragma unroll
-        for (int r = 0; r < kGroups; ++r) px[r] = load4(bg + r * kWavePx);
+        for (int r = 0; r < kGroups; ++r) {
+            if (!tail || q_lane + r * kWavePx + kLaneNPx <= n_px) {
+                px[r] = load4(bg + r * kWavePx);
+            } else {
+#pragma unroll
+                for (int j = 0; j < kLaneNPx; ++j)
+                    px[r][j] = q_lane + r * kWavePx + j < n_px ? load1(bg + r * kWavePx + j) : 0u;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < kGroups; ++r)
 #pragma unroll
@@ -417,7 +430,15 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
     // ---- the canvas is written exactly once: four coalesced 1 KiB stores per page ----
     gptr out = reinterpret_cast<gptr>(job.out) + q_lane;
 #pragma unroll
-    for (int r = 0; r < kGroups; ++r) store4(out + r * kWavePx, px[r]);
+    for (int r = 0; r < kGroups; ++r) {
+        if (!tail || q_lane + r * kWavePx + kLaneNPx <= n_px) {
+            store4(out + r * kWavePx, px[r]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kLaneNPx; ++j)
+                if (q_lane + r * kWavePx + j < n_px) store1(out + r * kWavePx + j, px[r][j]);
+        }
+    }
 }
 
 // Jobs arrive sorted by class: [0, n0) aligned+solid, [n0, n1) unaligned+solid, [n1, n2) aligned with
