@@ -191,8 +191,13 @@ __device__ __forceinline__ uint32_t clip8x4(int v0, int v1, int v2, int v3) {
     return (lo & 0xFFFFu) | (hi << 16);
 }
 
+// acc0 + (acc1 << 8) + (acc2 << 16) in Horner form, two v_lshl_add_u32 (hipcc re-associates the C
+// expression into two shifts and a three-operand add).
 __device__ __forceinline__ int combine(int a0, int a1, int a2) {
-    return (int)((((((uint32_t)a2 << 8) + (uint32_t)a1)) << 8) + (uint32_t)a0);  // two v_lshl_add_u32
+    int t;
+    asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(t) : "v"(a2), "v"(a1));
+    asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(t) : "v"(t), "v"(a0));
+    return t;
 }
 
 // Phase 1 of the MFMA kernel: R rows x C columns of the source, starting at pixel index `origin`,
@@ -315,7 +320,7 @@ __device__ __forceinline__ void store_pixels(const uint32_t (&w)[4], gptr dst, i
                             byte_perm(ba23, rg23, 0x05040100u), byte_perm(ba23, rg23, 0x07060302u)};
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-        if (ox < dw && oy + r < dh) dst[(size_t)(oy + r) * dw + ox] = unpremultiply_with(px[r], recip);
+        if (ox < dw && oy + r < dh) dst[(uint32_t)((oy + r) * dw + ox)] = unpremultiply_with(px[r], recip);  // < 2^31 px
 }
 
 __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__restrict__ jobs) {
