@@ -427,12 +427,16 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__rest
 hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int max_tiles, size_t lds_bytes,
                                 hipStream_t stream) {
     if (n_jobs <= 0 || max_tiles <= 0) return hipSuccess;
-    static size_t attr_set = 0;  // largest dynamic-LDS size the kernel has been opted in for
-    if (lds_bytes > attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_mfma_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsMfmaMaxLds);
+    // opt the kernel in for more than 64 KB of dynamic LDS, once per device of this process
+    static bool attr_set[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_mfma_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsMfmaMaxLds);
         if (e != hipSuccess) return e;
-        attr_set = kRsMfmaMaxLds;
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
     for (int first = 0; first < n_jobs; first += 65535) {  // grid.y limit
         const int n = std::min(65535, n_jobs - first);

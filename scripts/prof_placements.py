@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from image_transformation_amd import synthetic
 from image_transformation_amd.compositor import Atlas, CompositeBatch, SolidCanvas, coerce_placements
-size, objs, pl = synthetic.placements_workload(3840, 2160, 32, 3, "soft")
+size, objs, pl = synthetic.placements_workload(3840, 2160, 32, 3, os.environ.get("MIC_ALPHA", "soft"))
 atlas = Atlas(objs)
 plan = CompositeBatch(atlas, [SolidCanvas(size, synthetic.SOLID_BG)], [coerce_placements(atlas, pl)])
 out = plan.alloc_outputs()

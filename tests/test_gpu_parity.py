@@ -413,3 +413,58 @@ def test_ragged_and_extreme_shapes(gpu):
         want = oracle.composite(bg, objs, pl)
         got = out.cpu().numpy()
         assert np.array_equal(got, want), ((W, H, n), _maxdiff(got, want))
+
+
+def test_composite_fuzz_page_geometry(gpu):
+    """Random canvases against the oracle with everything that moves the 4 KiB page geometry: widths
+    that are / are not multiples of 4, sizes that are / are not multiples of a page (tail page through
+    the normal path), output and background pointers at odd 4-byte offsets inside a larger buffer
+    (first page partial: edge_page), solid / translucent-solid / image backgrounds, binary and soft
+    cutouts, and a few resampled layers."""
+    import torch
+    from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
+    rng = np.random.default_rng(2024)
+    objs = {i + 1: cases.synthetic.make_cutout(rng, int(rng.integers(3, 200)), int(rng.integers(3, 150)),
+                                               "binary" if i % 2 else "soft") for i in range(10)}
+    atlas = Atlas(objs)
+    dev = gpu.torch_device
+    for it in range(40):
+        W = int(rng.choice([64, 100, 255, 256, 257, 1000, 1024, 1027, 1365, 2048, 2051]))
+        H = int(rng.integers(1, 60))
+        n = int(rng.integers(0, 14))
+        pl = []
+        for _ in range(n):
+            oid = int(rng.integers(1, len(objs) + 1))
+            sh, sw = objs[oid].shape[:2]
+            if rng.random() < 0.2:  # resampled layer
+                sw, sh = max(1, int(sw * rng.uniform(0.4, 1.6))), max(1, int(sh * rng.uniform(0.4, 1.6)))
+            x1, y1 = int(rng.integers(-sw, W + 1)), int(rng.integers(-sh, H + 1))
+            pl.append({"object_id": oid, "box": [x1, y1, x1 + sw, y1 + sh]})
+        rows = coerce_placements(atlas, pl)
+        kind = it % 3
+        n_bytes = W * H * 4
+        # an output view at a random 4-byte offset inside a larger allocation
+        off = 4 * int(rng.integers(0, 1500))
+        big = torch.zeros(n_bytes + 8192, dtype=torch.uint8, device=dev)
+        out_view = big[off:off + n_bytes].view(H, W, 4)
+        if kind == 0:
+            colour = (38, 73, 115, 255)
+            bg_np = np.empty((H, W, 4), np.uint8); bg_np[:] = colour
+            canvas = SolidCanvas((W, H), colour)
+        elif kind == 1:
+            colour = (200, 10, 60, int(rng.integers(0, 255)))
+            bg_np = np.empty((H, W, 4), np.uint8); bg_np[:] = colour
+            canvas = SolidCanvas((W, H), colour)
+        else:
+            bg_np = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+            if it % 2:
+                bg_np[:, :, 3] = 255
+            boff = 4 * int(rng.integers(0, 1500))
+            bbig = torch.zeros(n_bytes + 8192, dtype=torch.uint8, device=dev)
+            canvas = bbig[boff:boff + n_bytes].view(H, W, 4)
+            canvas.copy_(torch.from_numpy(bg_np).to(dev))
+        got = composite_device(atlas, [canvas], [rows], outs=[out_view])[0].cpu().numpy()
+        want = oracle.composite(bg_np, objs, pl)
+        assert np.array_equal(got, want), (it, W, H, n, kind, off, _maxdiff(got, want))
+        # nothing outside the canvas was written
+        assert not big[:off].any() and not big[off + n_bytes:].any(), (it, "wrote outside the canvas")
