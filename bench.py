@@ -55,6 +55,47 @@ def cpu_baseline(objs, placements, size, budget_s=12.0, max_reps=5000):
                       f"{med * 1e3:.1f} ms, oracle/mic_oracle.c single thread, nproc={os.cpu_count()}"}
 
 
+def cpu_pillow(objs, placements, size, budget_s=5.0):
+    """when Pillow is installed on the box, the same composite through Pillow itself
+    (this file's own restatement of the reference's loop, compositor.py:6-22 -- the reference's files
+    are not here): the speed a user of the reference sees, and a cross-check of the port's number."""
+    try:
+        from PIL import Image
+    except ImportError:
+        return None
+    import numpy as np
+    from image_transformation_amd.synthetic import SOLID_BG
+
+    W, H = size
+    bg = Image.new("RGBA", (W, H), tuple(SOLID_BG))
+    imgs = {k: Image.fromarray(np.ascontiguousarray(v), "RGBA") for k, v in objs.items()}
+
+    def run():
+        canvas = bg.copy()
+        for p in placements:
+            obj = imgs.get(int(p["object_id"]))
+            if obj is None:
+                continue
+            x1, y1, x2, y2 = [int(v) for v in p["box"]]
+            o = obj.resize((max(1, x2 - x1), max(1, y2 - y1)), Image.LANCZOS)
+            canvas.alpha_composite(o, dest=(x1, y1))
+        return canvas
+
+    run()
+    times = []
+    t_all = time.perf_counter()
+    while (time.perf_counter() - t_all) < budget_s and len(times) < 200:
+        t0 = time.perf_counter()
+        run()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    import PIL
+    return {"value": round(W * H / med / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "pillow",
+            "sample": f"{len(times)} reps of the same composite through Pillow {PIL.__version__} (resize + alpha_composite "
+                      f"loop), median {med * 1e3:.1f} ms"}
+
+
 def cpu_baseline_threads(objs, placements, size, budget_s=8.0):
     """the same port, one image per core (the C call releases the GIL), different
     layouts of the batch round-robin.  Reported beside cpu_baseline, not instead of it."""
@@ -305,6 +346,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(objs, placements[0], size)
         result["cpu_baseline_all_cores"] = cpu_baseline_threads(objs, placements, size)
+        result["cpu_pillow"] = cpu_pillow(objs, placements[0], size)
     elif rank == 0:
         result["cpu_baseline"] = None
 
