@@ -90,6 +90,7 @@ SYMBOLS = {
     "mic_thumbnail_size": (ctypes.c_int, [ctypes.c_int32] * 4 + [_I32P, _I32P]),
     "mic_last_stats": (ctypes.c_int, [_P, ctypes.POINTER(Stats)]),
     "mic_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
+    "mic_profile_begin_sampled": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),
     "mic_profile_end": (ctypes.c_int, [_P, _P, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double),
                                        ctypes.POINTER(ctypes.c_double)]),
 }
@@ -162,8 +163,9 @@ class Context:
         check(lib().mic_last_stats(self.handle, ctypes.byref(s)))
         return s.as_dict()
 
-    def profile_begin(self, max_calls: int) -> None:
-        check(lib().mic_profile_begin(self.handle, int(max_calls)))
+    def profile_begin(self, max_calls: int, every: int = 1) -> None:
+        """Bracket every `every`-th call's kernels with HIP events (up to max_calls brackets)."""
+        check(lib().mic_profile_begin_sampled(self.handle, int(max_calls), int(every)))
 
     def profile_end(self):
         """-> (calls, composite kernel ms summed, resample passes ms summed); syncs the stream."""

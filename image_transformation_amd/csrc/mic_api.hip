@@ -137,7 +137,7 @@ struct mic_ctx {
     uint64_t next_atlas_uid = 1;
     // optional event brackets around the kernels (mic_profile_begin/end)
     std::vector<hipEvent_t> prof_events;  // 3 per call: before resample, before composite, after
-    int prof_calls = 0, prof_max = 0;
+    int prof_calls = 0, prof_max = 0, prof_every = 1, prof_seen = 0;
     bool profiling = false;
 };
 
@@ -606,6 +606,19 @@ struct mic_plan {
     void *tables_dev = nullptr;  // persistent plans: jobs | layers | h passes | v passes
     size_t off_layers = 0, off_f = 0, off_h = 0, off_v = 0, total = 0;
     mic_stats stats{};
+    // Persistent plans: the job table only depends on the output pointers, so the device copies for
+    // the last few sets of outputs are kept (callers rotate over a handful of output sets); a run onto
+    // a known set uploads nothing -- it is one kernel launch.
+    struct JobTable {
+        std::vector<uint64_t> outs;  // key: the canvases of that run, caller order
+        Job *dev = nullptr;
+        int class_end[3] = {0, 0, 0};
+        int pitch = 0;
+        uint64_t last_use = 0;
+    };
+    static constexpr int kJobTables = 4;
+    JobTable job_tables[kJobTables];
+    uint64_t run_counter = 0;
 };
 
 static void plan_offsets(mic_plan *P) {
@@ -757,54 +770,101 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         return MIC_OK;
     }
     if (int rc = adopt_stream(ctx, stream)) return rc;
-    int max_pages = 0;
-    P->ordered = P->jobs;  // this run's copy: the plan keeps the caller's own out_dev untouched
-    for (int ji = 0; ji < n_jobs; ++ji) {
-        Job &d = P->ordered[(size_t)ji];
-        if (outs) d.out = reinterpret_cast<uint64_t>(outs[ji]);
-        if (!d.out) return fail(MIC_ERR_INVALID, "job %d: null output canvas", ji);
-        if (d.out == d.bg) return fail(MIC_ERR_INVALID, "job %d: output aliases the background", ji);
-        if (d.out % 4 != 0) return fail(MIC_ERR_INVALID, "job %d: canvas pointers must be 4-byte aligned", ji);
-        // 4 KiB pages aligned to absolute address: one workgroup per page (see mic_internal.h)
-        d.px_shift = (int32_t)((d.out & 4095u) / 4);
-        d.n_pages = (int32_t)(((uint64_t)d.W * d.H + d.px_shift + kPagePx - 1) / kPagePx);
-        max_pages = std::max(max_pages, d.n_pages);
-    }
-    const int pitch = (max_pages + 7) / 8 * 8;
-    // sort the job table by kernel class (see launch_composite): 0 = aligned + solid opaque
-    // background (the pipeline's own canvases), 1 = unaligned + solid, 2 = aligned + other, 3 = rest
-    auto job_class = [](const Job &d) {
-        const bool aligned = d.W % 4 == 0 && d.out % 16 == 0;
-        const bool solid = d.bg == 0 && (d.bg_rgba >> 24) == 255u;
-        return (solid ? 0 : 2) + (aligned ? 0 : 1);
-    };
-    std::stable_sort(P->ordered.begin(), P->ordered.end(),
-                     [&](const Job &a, const Job &b) { return job_class(a) < job_class(b); });
-    int class_end[3] = {0, 0, 0};
-    for (const Job &d : P->ordered)
-        for (int c = job_class(d); c < 3; ++c) ++class_end[c];
-
-    // the job table always travels (output pointers change per run); the rest only for transient plans
-    const size_t upload = P->persistent ? sizeof(Job) * P->ordered.size() : P->total;
-    Slot *slot = nullptr;
-    if (int rc = acquire_slot(ctx, upload, &slot)) return rc;
-    char *hp = static_cast<char *>(slot->host);
-    memcpy(hp, P->ordered.data(), sizeof(Job) * P->ordered.size());
-    char *dp;
+    // ---- persistent plan onto a set of outputs it has seen: no table work, no upload ----
+    mic_plan::JobTable *slot_tab = nullptr;
     if (P->persistent) {
+        ++P->run_counter;
+        std::vector<uint64_t> key((size_t)n_jobs);
+        for (int ji = 0; ji < n_jobs; ++ji)
+            key[(size_t)ji] = outs ? reinterpret_cast<uint64_t>(outs[ji]) : P->jobs[(size_t)ji].out;
+        mic_plan::JobTable *lru = &P->job_tables[0];
+        for (auto &t : P->job_tables) {
+            if (t.dev && t.outs == key) {
+                slot_tab = &t;
+                break;
+            }
+            if (t.last_use < lru->last_use) lru = &t;
+        }
+        if (!slot_tab) {
+            if (!lru->dev) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&lru->dev), sizeof(Job) * (size_t)n_jobs));
+            lru->outs.clear();  // filled in below once the table is valid
+            slot_tab = lru;
+            slot_tab->pitch = 0;
+        }
+        slot_tab->last_use = P->run_counter;
+    }
+    const bool cached = slot_tab && !slot_tab->outs.empty();
+
+    int class_end[3] = {0, 0, 0};
+    int pitch = 0;
+    char *dp = nullptr;
+    if (cached) {
+        memcpy(class_end, slot_tab->class_end, sizeof class_end);
+        pitch = slot_tab->pitch;
         dp = static_cast<char *>(P->tables_dev);
     } else {
-        dp = static_cast<char *>(slot->dev);
-        if (!P->layers.empty()) memcpy(hp + P->off_layers, P->layers.data(), sizeof(Layer) * P->layers.size());
-        if (!P->pt.fused.empty()) memcpy(hp + P->off_f, P->pt.fused.data(), sizeof(RsMfma) * P->pt.fused.size());
-        if (!P->pt.h.empty()) memcpy(hp + P->off_h, P->pt.h.data(), sizeof(RsJob) * P->pt.h.size());
-        if (!P->pt.v.empty()) memcpy(hp + P->off_v, P->pt.v.data(), sizeof(RsJob) * P->pt.v.size());
-    }
-    HIP_TRY(hipMemcpyAsync(dp, slot->host, upload, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipEventRecord(slot->ev, stream));
-    slot->pending = true;
+        int max_pages = 0;
+        P->ordered = P->jobs;  // this run's copy: the plan keeps the caller's own out_dev untouched
+        for (int ji = 0; ji < n_jobs; ++ji) {
+            Job &d = P->ordered[(size_t)ji];
+            if (outs) d.out = reinterpret_cast<uint64_t>(outs[ji]);
+            if (!d.out) return fail(MIC_ERR_INVALID, "job %d: null output canvas", ji);
+            if (d.out == d.bg) return fail(MIC_ERR_INVALID, "job %d: output aliases the background", ji);
+            if (d.out % 4 != 0) return fail(MIC_ERR_INVALID, "job %d: canvas pointers must be 4-byte aligned", ji);
+            // 4 KiB pages aligned to absolute address: one workgroup per page (see mic_internal.h)
+            d.px_shift = (int32_t)((d.out & 4095u) / 4);
+            d.n_pages = (int32_t)(((uint64_t)d.W * d.H + d.px_shift + kPagePx - 1) / kPagePx);
+            max_pages = std::max(max_pages, d.n_pages);
+        }
+        pitch = (max_pages + 7) / 8 * 8;
+        // sort the job table by kernel class (see launch_composite): 0 = aligned + solid opaque
+        // background (the pipeline's own canvases), 1 = unaligned + solid, 2 = aligned + other, 3 = rest
+        auto job_class = [](const Job &d) {
+            const bool aligned = d.W % 4 == 0 && d.out % 16 == 0;
+            const bool solid = d.bg == 0 && (d.bg_rgba >> 24) == 255u;
+            return (solid ? 0 : 2) + (aligned ? 0 : 1);
+        };
+        std::vector<uint64_t> key;
+        if (slot_tab) {
+            key.resize((size_t)n_jobs);
+            for (int ji = 0; ji < n_jobs; ++ji) key[(size_t)ji] = P->ordered[(size_t)ji].out;
+        }
+        std::stable_sort(P->ordered.begin(), P->ordered.end(),
+                         [&](const Job &a, const Job &b) { return job_class(a) < job_class(b); });
+        for (const Job &d : P->ordered)
+            for (int c = job_class(d); c < 3; ++c) ++class_end[c];
 
-    const bool prof = ctx->profiling && ctx->prof_calls < ctx->prof_max;
+        // persistent plans upload the job table into the chosen cache slot; transient ones upload
+        // everything into the staging slot's device buffer
+        const size_t upload = P->persistent ? sizeof(Job) * P->ordered.size() : P->total;
+        Slot *slot = nullptr;
+        if (int rc = acquire_slot(ctx, upload, &slot)) return rc;
+        char *hp = static_cast<char *>(slot->host);
+        memcpy(hp, P->ordered.data(), sizeof(Job) * P->ordered.size());
+        void *upload_dst;
+        if (P->persistent) {
+            dp = static_cast<char *>(P->tables_dev);
+            upload_dst = slot_tab->dev;
+        } else {
+            dp = static_cast<char *>(slot->dev);
+            upload_dst = slot->dev;
+            if (!P->layers.empty()) memcpy(hp + P->off_layers, P->layers.data(), sizeof(Layer) * P->layers.size());
+            if (!P->pt.fused.empty()) memcpy(hp + P->off_f, P->pt.fused.data(), sizeof(RsMfma) * P->pt.fused.size());
+            if (!P->pt.h.empty()) memcpy(hp + P->off_h, P->pt.h.data(), sizeof(RsJob) * P->pt.h.size());
+            if (!P->pt.v.empty()) memcpy(hp + P->off_v, P->pt.v.data(), sizeof(RsJob) * P->pt.v.size());
+        }
+        HIP_TRY(hipMemcpyAsync(upload_dst, slot->host, upload, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(slot->ev, stream));
+        slot->pending = true;
+        if (slot_tab) {
+            slot_tab->outs = std::move(key);
+            memcpy(slot_tab->class_end, class_end, sizeof class_end);
+            slot_tab->pitch = pitch;
+        }
+    }
+    const Job *jobs_dev = P->persistent ? slot_tab->dev : reinterpret_cast<const Job *>(dp);
+
+    const bool prof = ctx->profiling && ctx->prof_calls < ctx->prof_max && (ctx->prof_seen++ % ctx->prof_every) == 0;
     hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], stream));
     HIP_TRY(launch_resample_mfma(reinterpret_cast<const RsMfma *>(dp + P->off_f), (int)P->pt.fused.size(),
@@ -814,8 +874,8 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + P->off_v), (int)P->pt.v.size(),
                               P->pt.max_v_out_w, P->pt.max_v_out_h, stream));
     if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
-    HIP_TRY(launch_composite(reinterpret_cast<const Job *>(dp), reinterpret_cast<const Layer *>(dp + P->off_layers),
-                             n_jobs, class_end, pitch, stream));
+    HIP_TRY(launch_composite(jobs_dev, reinterpret_cast<const Layer *>(dp + P->off_layers), n_jobs, class_end, pitch,
+                             stream));
     if (prof) {
         HIP_TRY(hipEventRecord(pe[2], stream));
         ++ctx->prof_calls;
@@ -864,6 +924,8 @@ extern "C" int mic_plan_destroy(mic_plan *plan) {
     }
     if (plan->scratch) (void)hipFree(plan->scratch);
     if (plan->tables_dev) (void)hipFree(plan->tables_dev);
+    for (auto &t : plan->job_tables)
+        if (t.dev) (void)hipFree(t.dev);
     delete plan;
     return MIC_OK;
 }
@@ -880,9 +942,14 @@ extern "C" int mic_last_stats(const mic_ctx *ctx, mic_stats *out) {
     return MIC_OK;
 }
 
-extern "C" int mic_profile_begin(mic_ctx *ctx, int max_calls) {
+extern "C" int mic_profile_begin(mic_ctx *ctx, int max_calls) { return mic_profile_begin_sampled(ctx, max_calls, 1); }
+
+extern "C" int mic_profile_begin_sampled(mic_ctx *ctx, int max_calls, int every) {
     if (int rc = ctx_enter(ctx)) return rc;
-    if (max_calls <= 0 || max_calls > (1 << 20)) return fail(MIC_ERR_INVALID, "mic_profile_begin: bad max_calls");
+    if (max_calls <= 0 || max_calls > (1 << 20) || every <= 0)
+        return fail(MIC_ERR_INVALID, "mic_profile_begin: bad max_calls / every");
+    ctx->prof_every = every;
+    ctx->prof_seen = 0;
     while ((int)ctx->prof_events.size() < max_calls * 3) {
         hipEvent_t ev;
         HIP_TRY(hipEventCreate(&ev));

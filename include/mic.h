@@ -194,6 +194,9 @@ int mic_plan_stats(const mic_plan *plan, mic_stats *out);
  * kernel (and, separately, its resample passes) with an event pair.  mic_profile_end waits for
  * the stream, then reports the number of bracketed calls and the summed durations in ms.       */
 int mic_profile_begin(mic_ctx *ctx, int max_calls);
+/* Same, bracketing only every `every`-th call (an event pair between two back-to-back kernels costs
+ * a few microseconds of idle GPU; sampling keeps the timed loop representative).                 */
+int mic_profile_begin_sampled(mic_ctx *ctx, int max_calls, int every);
 int mic_profile_end(mic_ctx *ctx, void *stream, int *n_calls, double *composite_ms, double *resample_ms);
 
 #ifdef __cplusplus
