@@ -468,3 +468,44 @@ def test_composite_fuzz_page_geometry(gpu):
         assert np.array_equal(got, want), (it, W, H, n, kind, off, _maxdiff(got, want))
         # nothing outside the canvas was written
         assert not big[:off].any() and not big[off + n_bytes:].any(), (it, "wrote outside the canvas")
+
+
+def test_plan_job_table_cache(gpu):
+    """A persistent plan keeps device job tables for the last four output sets: cycling over six sets
+    (hits, misses and evictions) must give the same pixels every time, and a run must never write into
+    a set it was not asked to."""
+    import torch
+    from image_transformation_amd import flex
+    from image_transformation_amd.compositor import Atlas, CompositeBatch, SolidCanvas, coerce_placements
+    size, objs, layouts = cases.synthetic.c3_workload("binary", seed=11, n_layouts=3)
+    size = (1283, 517)  # small, unaligned width: both kernel classes of a mixed batch stay cheap
+    atlas = Atlas(objs)
+    rows = [coerce_placements(atlas, flex.layout_to_placements(l, atlas, size)) for l in layouts]
+    canvases = [SolidCanvas(size, (38, 73, 115, 255)), SolidCanvas(size, (1, 2, 3, 200)), SolidCanvas(size, (9, 9, 9, 255))]
+    plan = CompositeBatch(atlas, canvases, rows)
+    want = None
+    sets = [plan.alloc_outputs() for _ in range(6)]
+    for s in sets:
+        for t in s:
+            t.zero_()
+    order = [0, 1, 0, 2, 3, 4, 5, 0, 1, 5, 5, 2]
+    used = set()
+    for k in order:
+        plan.run(sets[k])
+        used.add(k)
+        got = [t.cpu().numpy() for t in sets[k]]
+        if want is None:
+            want = got
+            bgs = [np.empty((size[1], size[0], 4), np.uint8) for _ in canvases]
+            for b, c in zip(bgs, canvases):
+                b[:] = np.asarray(c.rgba, np.uint8)
+            for g, b, l in zip(got, bgs, layouts):
+                assert np.array_equal(g, oracle.composite(b, objs, flex.layout_to_placements(l, atlas, size)))
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w), k
+        for j, s in enumerate(sets):  # sets not run yet are still zero
+            if j not in used:
+                assert not any(bool(t.any()) for t in s), (k, j)
+        for t in sets[k]:
+            t.zero_()
+            used.discard(k)
