@@ -108,15 +108,17 @@ def pack_blob(objects: Mapping[int, Any], pin: bool = False):
     nbytes = ctypes.c_size_t()
     _native.check(lib.mic_atlas_blob_size(n, _i32p(ws), _i32p(hs), ctypes.byref(nbytes)))
     torch = _torch()
-    host = torch.zeros(nbytes.value, dtype=torch.uint8)
-    if pin and torch.cuda.is_available():
-        host = host.pin_memory()
-    host_np = host.numpy()
+    # numpy, not torch.zeros: a torch CPU fill fans out over every core of the host (256 on the GPU
+    # boxes) and the thread wake-up alone cost ~40 ms per atlas
+    host_np = np.zeros(nbytes.value, np.uint8)
     offs = np.zeros(max(n, 1), np.uint64)
     _native.check(lib.mic_atlas_blob_layout(n, _i32p(ids_a), _i32p(ws), _i32p(hs), _P(host_np.ctypes.data),
                                             nbytes.value, offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
     for a, off in zip(arrs, offs):
         host_np[int(off):int(off) + a.size] = a.reshape(-1)
+    host = torch.from_numpy(host_np)
+    if pin and torch.cuda.is_available():
+        host = host.pin_memory()
     return host
 
 
@@ -145,8 +147,8 @@ class Atlas(Mapping):
 
     def __init__(self, objects: Mapping[int, Any], device: Optional[int] = None):
         self.ctx = _native.context(device)
-        host = pack_blob(objects, pin=True)
-        self._init_from_blob(host.to(self.ctx.torch_device), header=host.numpy())
+        host = pack_blob(objects)
+        self._init_from_blob(_upload(host.numpy(), self.ctx), header=host.numpy())
 
     def _init_from_blob(self, blob, header: Optional[np.ndarray] = None):
         self.blob = blob  # torch uint8 tensor on the device; owns the memory
