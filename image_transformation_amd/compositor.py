@@ -315,6 +315,32 @@ def _make_job(size, bg_dev_ptr, bg_rgba, placement_arr, n_place, out_ptr) -> Job
     return j
 
 
+def _build_jobs(atlas: "Atlas", canvases, placement_rows):
+    """-> (ctypes Job array with null outputs, [(W, H)...], objects to keep alive while it is used)."""
+    torch = _torch()
+    n = len(canvases)
+    jobs = (Job * max(n, 1))()
+    sizes: List[Tuple[int, int]] = []
+    keep: List[Any] = []
+    for i, (cv, rows) in enumerate(zip(canvases, placement_rows)):
+        if isinstance(cv, SolidCanvas):
+            W, H = cv.size
+            bg_ptr, rgba = None, cv.rgba
+        else:
+            if cv.dtype != torch.uint8 or cv.dim() != 3 or cv.shape[2] != 4 or not cv.is_contiguous():
+                raise ValueError("device canvas must be a contiguous uint8 (H, W, 4) tensor")
+            if cv.device != atlas.ctx.torch_device:
+                raise ValueError("canvas lives on another device than the atlas")
+            H, W = int(cv.shape[0]), int(cv.shape[1])
+            bg_ptr, rgba = cv.data_ptr(), (0, 0, 0, 0)
+            keep.append(cv)
+        parr = _fill_placements(rows)
+        jobs[i] = _make_job((W, H), bg_ptr, rgba, parr, len(rows), None)
+        keep.append(parr)
+        sizes.append((W, H))
+    return jobs, sizes, keep
+
+
 class CompositeBatch:
     """A batch of composite jobs resolved once into a persistent libmic plan (mic_plan_create):
     device layer records, resample tables and scratch live with the plan.  run() re-executes all
@@ -336,25 +362,8 @@ class CompositeBatch:
         self.n = len(canvases)
         if len(placement_rows) != self.n:
             raise ValueError("one placement list per canvas")
-        jobs = (Job * max(self.n, 1))()
-        self.sizes: List[Tuple[int, int]] = []
-        self._keep: List[Any] = [atlas]
-        for i, (cv, rows) in enumerate(zip(canvases, placement_rows)):
-            if isinstance(cv, SolidCanvas):
-                W, H = cv.size
-                bg_ptr, rgba = None, cv.rgba
-            else:
-                if cv.dtype != torch.uint8 or cv.dim() != 3 or cv.shape[2] != 4 or not cv.is_contiguous():
-                    raise ValueError("device canvas must be a contiguous uint8 (H, W, 4) tensor")
-                if cv.device != self.ctx.torch_device:
-                    raise ValueError("canvas lives on another device than the atlas")
-                H, W = int(cv.shape[0]), int(cv.shape[1])
-                bg_ptr, rgba = cv.data_ptr(), (0, 0, 0, 0)
-                self._keep.append(cv)
-            parr = _fill_placements(rows)
-            jobs[i] = _make_job((W, H), bg_ptr, rgba, parr, len(rows), None)
-            self._keep.append(parr)
-            self.sizes.append((W, H))
+        jobs, self.sizes, keep = _build_jobs(atlas, canvases, placement_rows)
+        self._keep: List[Any] = [atlas] + keep
         atl = (_P * 1)(atlas.handle)
         h = _P()
         with torch.cuda.device(self.ctx.torch_device):
@@ -407,9 +416,33 @@ class CompositeBatch:
 def composite_device(atlas: Atlas, canvases: Sequence[Union[SolidCanvas, Any]],
                      placement_rows: Sequence[Sequence[Tuple[int, int, int, int, int]]],
                      outs: Optional[Sequence[Any]] = None, filter: int = LANCZOS):
-    """Batch composite, everything device-resident (see CompositeBatch).  Returns the list of output
-    canvases (torch uint8 (H, W, 4)); work is enqueued on torch's current stream."""
-    return CompositeBatch(atlas, canvases, placement_rows, filter).run(outs)
+    """One-shot batch composite, everything device-resident: one mic_composite_batch call (tables go
+    through the context's staging ring, resampled layers through its arena -- no allocation, no
+    synchronisation).  Returns the list of output canvases (torch uint8 (H, W, 4)); work is enqueued
+    on torch's current stream.  Callers that re-run the same batch should keep a CompositeBatch."""
+    if filter not in _FILTERS:
+        raise ValueError(f"unknown filter {filter}")
+    if len(placement_rows) != len(canvases):
+        raise ValueError("one placement list per canvas")
+    torch = _torch()
+    ctx = atlas.ctx
+    jobs, sizes, keep = _build_jobs(atlas, canvases, placement_rows)
+    if outs is None:
+        outs = [torch.empty((H, W, 4), dtype=torch.uint8, device=ctx.torch_device) for (W, H) in sizes]
+    if len(outs) != len(sizes):
+        raise ValueError("one output canvas per job")
+    for i, out in enumerate(outs):
+        W, H = sizes[i]
+        if tuple(out.shape) != (H, W, 4) or out.dtype != torch.uint8 or not out.is_contiguous() \
+                or out.device != ctx.torch_device:
+            raise ValueError("output canvas has the wrong shape/dtype/device")
+        jobs[i].out_dev = out.data_ptr()
+    atl = (_P * 1)(atlas.handle)
+    with torch.cuda.device(ctx.torch_device):
+        _native.check(_native.lib().mic_composite_batch(ctx.handle, 1, atl, len(sizes), jobs, filter,
+                                                        _P(ctx.stream_ptr())))
+    del keep
+    return list(outs)
 
 
 def composite(background_img: Image.Image, object_images: Mapping[int, Image.Image],
