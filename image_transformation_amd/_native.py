@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libmic.so")
 
 LANCZOS = 0
 BILINEAR = 1
+ERR_FORMAT = -5
 ERR_UNSUPPORTED = -6
 
 
@@ -87,6 +88,8 @@ SYMBOLS = {
                                               ctypes.POINTER(ctypes.c_uint8), ctypes.c_int32, _P]),
     "mic_flex_place": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, _I32P, _I32P, _I32P,
                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _I32P, _I32P, _I32P]),
+    "mic_render": (ctypes.c_int, [_P, _P, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, _P,
+                                  ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, _P, _P, _I32P]),
     "mic_thumbnail_size": (ctypes.c_int, [ctypes.c_int32] * 4 + [_I32P, _I32P]),
     "mic_last_stats": (ctypes.c_int, [_P, ctypes.POINTER(Stats)]),
     "mic_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),

@@ -474,6 +474,41 @@ def _layout_rows(layout_json: Any, images: Mapping[int, Any], atlas: "Atlas", si
     return coerce_placements(atlas, flex.layout_to_placements(layout_json, images, size))
 
 
+def _render_native(layout_json: Any, atlas: "Atlas", canvas: Any, size: Tuple[int, int], filter: int):
+    """mic_render: Flex JSON text -> boxes -> composite inside libmic.  None when the layout is not a
+    Flex tree or the native placer leaves it to flex.py (which also raises the reference's errors)."""
+    if isinstance(layout_json, (bytes, str)):
+        text = layout_json.encode("utf-8") if isinstance(layout_json, str) else layout_json
+    elif isinstance(layout_json, dict) and "root" in layout_json:
+        try:
+            text = json.dumps(layout_json, separators=(",", ":")).encode("utf-8")
+        except (TypeError, ValueError):
+            return None
+    else:
+        return None
+    if filter not in _FILTERS:
+        raise ValueError(f"unknown filter {filter}")
+    torch = _torch()
+    ctx = atlas.ctx
+    W, H = size
+    if isinstance(canvas, SolidCanvas):
+        bg_ptr, rgba = None, (ctypes.c_uint8 * 4)(*canvas.rgba)
+    else:
+        if canvas.dtype != torch.uint8 or canvas.dim() != 3 or canvas.shape[2] != 4 or not canvas.is_contiguous():
+            raise ValueError("device canvas must be a contiguous uint8 (H, W, 4) tensor")
+        if canvas.device != ctx.torch_device:
+            raise ValueError("canvas lives on another device than the atlas")
+        bg_ptr, rgba = canvas.data_ptr(), (ctypes.c_uint8 * 4)(0, 0, 0, 0)
+    out = torch.empty((H, W, 4), dtype=torch.uint8, device=ctx.torch_device)
+    with torch.cuda.device(ctx.torch_device):
+        rc = _native.lib().mic_render(ctx.handle, atlas.handle, text, len(text), W, H, _P(bg_ptr) if bg_ptr else None,
+                                      rgba, filter, _P(out.data_ptr()), _P(ctx.stream_ptr()), None)
+    if rc in (_native.ERR_UNSUPPORTED, _native.ERR_FORMAT):
+        return None
+    _native.check(rc)
+    return out
+
+
 def _canvas_size(canvas) -> Tuple[int, int]:
     if isinstance(canvas, (SolidCanvas, Image.Image)):
         return canvas.size
@@ -491,6 +526,10 @@ def render(layout_json: Any, objects: Mapping[int, Any], canvas: Any, *, filter:
     canvas: an RGBA PIL image, a SolidCanvas, or a device uint8 (H, W, 4) tensor."""
     atlas = _as_atlas(objects)
     size = _canvas_size(canvas)
+    if not isinstance(canvas, Image.Image):
+        out = _render_native(layout_json, atlas, canvas, size, filter)  # place + composite in one ABI call
+        if out is not None:
+            return out if as_tensor else _to_pil(out)
     rows = _layout_rows(layout_json, objects if not isinstance(objects, Atlas) else atlas, atlas, size)
     if isinstance(canvas, Image.Image):
         if not rows and not as_tensor:

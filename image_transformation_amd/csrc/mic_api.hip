@@ -895,6 +895,47 @@ extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const
     return plan_submit(&P, nullptr, stream);
 }
 
+extern "C" int mic_render(mic_ctx *ctx, mic_atlas *atlas, const char *layout_json, size_t len, int32_t width,
+                          int32_t height, const void *bg_dev, const uint8_t bg_rgba[4], int filter, void *out_dev,
+                          void *stream_v, int32_t *n_placed) {
+    if (int rc = ctx_enter(ctx)) return rc;
+    if (!atlas || !layout_json || !out_dev || width <= 0 || height <= 0 || (!bg_dev && !bg_rgba))
+        return fail(MIC_ERR_INVALID, "mic_render: bad arguments");
+    if (atlas->ctx != ctx) return fail(MIC_ERR_INVALID, "mic_render: atlas belongs to another context");
+    // the sizes the placer sees: one entry per id, the first occurrence (what a dict would hold)
+    const size_t n = atlas->index.size();
+    std::vector<int32_t> ids, ws, hs;
+    ids.reserve(n); ws.reserve(n); hs.reserve(n);
+    for (size_t i = 0; i < atlas->entries.size(); ++i) {
+        const BlobEntry &e = atlas->entries[i];
+        if (atlas->index.at(e.id) != (int)i) continue;
+        ids.push_back(e.id); ws.push_back(e.w); hs.push_back(e.h);
+    }
+    std::vector<int32_t> oi, ob;
+    std::string err;
+    const int frc = flex_place(layout_json, len, (int)ids.size(), ids.data(), ws.data(), hs.data(), width, height, &oi,
+                               &ob, &err);
+    if (frc == kFlexMalformed) return fail(MIC_ERR_FORMAT, "mic_render: %s", err.c_str());
+    if (frc == kFlexUnsupported)
+        return fail(MIC_ERR_UNSUPPORTED, "mic_render: layout uses features only the Python placer mirrors");
+    if (n_placed) *n_placed = (int32_t)oi.size();
+    std::vector<mic_placement> pl(oi.size());
+    for (size_t i = 0; i < oi.size(); ++i) {
+        pl[i].atlas = 0;
+        pl[i].object_id = oi[i];
+        for (int k = 0; k < 4; ++k) pl[i].box[k] = ob[4 * i + k];
+    }
+    mic_job job{};
+    job.width = width; job.height = height;
+    job.bg_dev = bg_dev;
+    if (bg_rgba) memcpy(job.bg_rgba, bg_rgba, 4);
+    job.n_placements = (int32_t)pl.size();
+    job.placements = pl.data();
+    job.out_dev = out_dev;
+    mic_atlas *atl[1] = {atlas};
+    return mic_composite_batch(ctx, 1, atl, 1, &job, filter, stream_v);
+}
+
 extern "C" int mic_plan_create(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,
                                const mic_job *jobs, int filter, mic_plan **out) {
     if (int rc = ctx_enter(ctx)) return rc;

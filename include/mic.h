@@ -171,6 +171,16 @@ int mic_flex_place(const char *layout_json, size_t len, int n_objects, const int
                    const int32_t *widths, const int32_t *heights, int32_t canvas_w, int32_t canvas_h,
                    int32_t capacity, int32_t *out_ids, int32_t *out_boxes_xyxy, int32_t *out_count);
 
+/* render(layout_json, objects, canvas) in one call (north_star; macro_placement_test.py:1495-1498 +
+ * :1511): the Flex tree is placed from (0,0) over the whole canvas with the atlas' cutout sizes,
+ * clamped, and composited -- mic_flex_place + mic_composite_batch without a round trip through the
+ * caller.  bg_dev: device RGBA background of width x height, or NULL for the solid colour bg_rgba.
+ * Same status codes as mic_flex_place (MIC_ERR_UNSUPPORTED: place it with the Python mirror and call
+ * mic_composite_batch); *n_placed (optional) receives the number of placements the tree produced. */
+int mic_render(mic_ctx *ctx, mic_atlas *atlas, const char *layout_json, size_t len, int32_t width,
+               int32_t height, const void *bg_dev, const uint8_t bg_rgba[4], int filter, void *out_dev,
+               void *stream, int32_t *n_placed);
+
 /* ---- helpers ----------------------------------------------------------------------------- */
 /* Pillow Image.thumbnail size rule (macro_placement_test.py:194). */
 int mic_thumbnail_size(int32_t w, int32_t h, int32_t req_w, int32_t req_h, int32_t *out_w,
