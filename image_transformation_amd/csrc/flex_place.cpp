@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <memory>
 #include <string>
@@ -196,10 +197,65 @@ struct Placer {
     }
     static bool is_object_node(const JValue &n) { return n.get("object_id") != nullptr; }
 
+    static bool keys_within(const JValue &o, std::initializer_list<const char *> allowed) {
+        for (size_t a = 0; a < o.obj.size(); ++a) {
+            bool known = false;
+            for (const char *k : allowed) known = known || o.obj[a].first == k;
+            if (!known) return false;
+            for (size_t b = a + 1; b < o.obj.size(); ++b)
+                if (o.obj[a].first == o.obj[b].first) return false;  // duplicate keys: Python keeps the last
+        }
+        return true;
+    }
+    static void validate_hints(const JValue &node) {
+        if (const JValue *pin = node.get("pin")) {
+            if (pin->kind != JValue::Null) {
+                if (pin->kind != JValue::Object || !keys_within(*pin, {"horizontal", "vertical"})) throw Unsupported{};
+                for (const auto &kv : pin->obj) {
+                    const JValue &v = *kv.second;
+                    if (v.kind == JValue::Null) continue;
+                    if (v.kind != JValue::String || (v.s != "start" && v.s != "center" && v.s != "end")) throw Unsupported{};
+                }
+            }
+        }
+        if (const JValue *off = node.get("offset_px")) {
+            if (off->kind != JValue::Null) {
+                if (off->kind != JValue::Object || !keys_within(*off, {"x", "y"})) throw Unsupported{};
+                for (const auto &kv : off->obj)
+                    if (kv.second->kind != JValue::Int) throw Unsupported{};
+            }
+        }
+        if (const JValue *st = node.get("stick_to")) {
+            if (st->kind != JValue::Null) {
+                if (st->kind != JValue::Object || !keys_within(*st, {"edges", "margin_px"})) throw Unsupported{};
+                const JValue *edges = st->get("edges");
+                if (!edges || edges->kind != JValue::Array || edges->arr.empty()) throw Unsupported{};
+                bool seen[4] = {false, false, false, false};  // left, right, top, bottom
+                for (const JPtr &e : edges->arr) {
+                    if (e->kind != JValue::String) throw Unsupported{};
+                    std::string low = e->s;
+                    for (char &ch : low) {
+                        if ((unsigned char)ch >= 0x80) throw Unsupported{};  // str.lower() on non-ASCII: Python's business
+                        if (ch >= 'A' && ch <= 'Z') ch = (char)(ch - 'A' + 'a');
+                    }
+                    const int idx = low == "left" ? 0 : low == "right" ? 1 : low == "top" ? 2 : low == "bottom" ? 3 : -1;
+                    if (idx < 0 || seen[idx]) throw Unsupported{};
+                    seen[idx] = true;
+                }
+                if ((seen[0] && seen[1]) || (seen[2] && seen[3])) throw Unsupported{};
+                if (const JValue *m = st->get("margin_px"))
+                    if (m->kind != JValue::Int || m->i < 0) throw Unsupported{};
+            }
+        }
+    }
+
     struct Pad { long long l = 0, r = 0, t = 0, b = 0; };
     static Pad object_padding(const JValue &node) {
-        for (const char *k : {"pin", "offset_px", "stick_to"})
-            if (node.get(k)) throw Unsupported{};  // validated (and echoed) by the Python placer
+        // pin / offset_px / stick_to never move a box (macro_placement_test.py:767-811 nets out to
+        // slot + padding), but the reference validates them (:286-372) and raises on anything odd.
+        // Plainly valid values are accepted here; everything else goes to the Python placer, which
+        // raises the reference's errors.
+        validate_hints(node);
         Pad pad;
         const JValue *v = node.get("padding_px");
         if (!v || v->kind == JValue::Null) return pad;

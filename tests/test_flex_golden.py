@@ -70,7 +70,7 @@ def test_native_placer_matches_reference_or_declines(flex_golden):
         # the JSON text form (a VLM reply) gives the same answer, whitespace and key order aside
         text = _json.dumps(case["layout"], indent=2, sort_keys=True)
         assert flex.native_boxes(text, sizes, tuple(case["canvas"])) == want, case["name"]
-    assert accepted >= 0.6 * (len(flex_golden["cases"]) + len(flex_golden["kat"])), accepted
+    assert accepted >= 0.95 * (len(flex_golden["cases"]) + len(flex_golden["kat"])), accepted
     sq = {k: tuple(v) for k, v in cases.SQUARESPACE_SIZES.items()}
     for row in flex_golden["errors"]:  # every malformed object field is left to flex.py (which raises)
         node = dict({"object_id": 2}, **row["fields"])
