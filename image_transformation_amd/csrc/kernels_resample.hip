@@ -326,7 +326,8 @@ __device__ __forceinline__ void store_pixels(const uint32_t (&w)[4], gptr dst, i
 __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__restrict__ jobs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
     const RsMfma J = jobs[blockIdx.y];
-    const int tile = J.tile0 + blockIdx.x;  // a layer is launched in slices of kRsTilesPerEntry tiles
+    // XCD-aware tile order (see RsMfma): blockIdx.x & 7 is the XCD this workgroup lands on
+    const int tile = (((int)blockIdx.x + J.xcd_rot) & 7) * (4 * J.n_entries) + 4 * J.entry + ((int)blockIdx.x >> 3);
     if (tile >= J.tiles_x * J.tiles_y) return;
     const int tyi = tile / J.tiles_x, txi = tile - tyi * J.tiles_x;
     const int xt0 = txi * J.tx16, yt0 = tyi * J.ty16;
@@ -440,8 +441,8 @@ hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int max_tile
     }
     for (int first = 0; first < n_jobs; first += 65535) {  // grid.y limit
         const int n = std::min(65535, n_jobs - first);
-        hipLaunchKernelGGL(resample_mfma_kernel, dim3((unsigned)max_tiles, (unsigned)n), dim3(256), lds_bytes, stream,
-                           jobs_dev + first);
+        hipLaunchKernelGGL(resample_mfma_kernel, dim3((unsigned)kRsTilesPerEntry, (unsigned)n), dim3(256), lds_bytes,
+                           stream, jobs_dev + first);
     }
     return hipGetLastError();
 }

@@ -471,6 +471,7 @@ struct ResizePlan {
 
 struct PassTables {
     std::vector<RsMfma> fused;
+    int fused_layers = 0;
     int fused_max_tiles = 0;
     size_t fused_lds = 0;
     std::vector<RsJob> h, v;
@@ -542,8 +543,10 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             f.tiles_x = (fh.tiles + p.tx16 - 1) / p.tx16; f.tiles_y = (fv.tiles + p.ty16 - 1) / p.ty16;
             f.pitch_c = p.pitch_c; f.pitch_r = p.pitch_r; f.rows16 = p.rows16;
             const int n_tiles = f.tiles_x * f.tiles_y;
-            for (f.tile0 = 0; f.tile0 < n_tiles; f.tile0 += kRsTilesPerEntry) pt->fused.push_back(f);
-            pt->fused_max_tiles = std::max(pt->fused_max_tiles, std::min(n_tiles, kRsTilesPerEntry));
+            f.n_entries = (n_tiles + kRsTilesPerEntry - 1) / kRsTilesPerEntry;
+            f.xcd_rot = pt->fused_layers++ & 7;  // the XCD that gets a layer's short last band rotates
+            for (f.entry = 0; f.entry < f.n_entries; ++f.entry) pt->fused.push_back(f);
+            pt->fused_max_tiles = kRsTilesPerEntry;
             pt->fused_lds = std::max(pt->fused_lds, rs_mfma_lds_bytes(f.rows16, f.pitch_c, f.tx16, f.pitch_r));
             continue;
         }

@@ -83,9 +83,14 @@ struct alignas(16) RsMfma {
     int32_t tiles_x, tiles_y;
     int32_t pitch_c, pitch_r;      // bytes per row of a source plane / per column of an intermediate plane
     int32_t rows16;                // rows of a source plane (multiple of 16)
-    int32_t tile0;                 // first workgroup tile of this table entry
+    // A layer with more than kRsTilesPerEntry tiles takes several table entries (grid.y); workgroup
+    // bx of entry e works on tile ((bx + xcd_rot) & 7) * 4 n_entries + 4 e + (bx >> 3): workgroups
+    // are dealt round-robin over the 8 XCDs, so each XCD gets a contiguous band of the layer's tiles
+    // and neighbouring tiles (which share their source halo) share an L2.
+    int32_t entry, n_entries, xcd_rot;
+    int32_t pad[2];
 };
-static_assert(sizeof(RsMfma) == 112, "RsMfma layout");
+static_assert(sizeof(RsMfma) == 128, "RsMfma layout");
 inline size_t rs_mfma_lds_bytes(int rows16, int pitch_c, int tx16, int pitch_r) {
     return 4 * ((size_t)rows16 * pitch_c + (size_t)16 * tx16 * pitch_r) + 64;  // + slack for chunk over-reads
 }
