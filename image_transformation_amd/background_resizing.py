@@ -16,13 +16,13 @@ import numpy as np
 from PIL import Image
 
 from . import _native
-from .compositor import SolidCanvas, _image_to_array, _to_pil, _upload
+from .compositor import SolidCanvas, _image_to_array, _to_pil, _upload, open_rgba
 
 _P = ctypes.c_void_p
 
 
 def _load_background_rgba(background_path: str) -> Image.Image:
-    return Image.open(background_path).convert("RGBA")
+    return open_rgba(background_path)
 
 
 def median_color_device(rgba_dev, ctx: Optional[_native.Context] = None) -> Tuple[int, int, int]:

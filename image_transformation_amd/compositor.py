@@ -35,6 +35,37 @@ def _torch():
     return torch
 
 
+class _DecodeCache:
+    """Decoded RGBA images by (path, mtime, size).  The reference decodes every cutout for the contact
+    sheet and again for every iteration's load_object_images (macro_placement_test.py:1414, 1493,
+    1679); PNG decode is most of the host time left around the path, so a file that has not changed
+    is decoded once per process.  Entries are returned as copies (callers may mutate PIL images)."""
+    _items: "Dict[Tuple[str, int, int], Image.Image]" = {}
+    _bytes = 0
+    LIMIT = 512 << 20
+
+    @classmethod
+    def open_rgba(cls, path) -> Image.Image:
+        p = os.fspath(path)
+        st = os.stat(p)  # raises FileNotFoundError like Image.open
+        key = (os.path.abspath(p), st.st_mtime_ns, st.st_size)
+        im = cls._items.get(key)
+        if im is None:
+            im = Image.open(p).convert("RGBA")
+            nbytes = im.size[0] * im.size[1] * 4
+            if cls._bytes + nbytes > cls.LIMIT:
+                cls._items.clear()
+                cls._bytes = 0
+            cls._items[key] = im
+            cls._bytes += nbytes
+        return im.copy()
+
+
+def open_rgba(path) -> Image.Image:
+    """Image.open(path).convert("RGBA") through the per-process decode cache."""
+    return _DecodeCache.open_rgba(path)
+
+
 def _image_to_array(img: Image.Image) -> np.ndarray:
     """RGBA PIL image -> (H, W, 4) uint8 (a copy of the raw bytes; no arithmetic)."""
     if img.mode != "RGBA":
@@ -251,7 +282,7 @@ def load_object_images(results_json_path: str) -> Dict[int, Image.Image]:
     base = os.path.dirname(results_json_path)
     out = ObjectImages()
     for it in items:
-        out[int(it["object_id"])] = Image.open(os.path.join(base, it["filename"])).convert("RGBA")
+        out[int(it["object_id"])] = open_rgba(os.path.join(base, it["filename"]))
     return out
 
 

@@ -19,7 +19,7 @@ import numpy as np
 from PIL import Image, ImageDraw, ImageFont
 
 from . import _native
-from .compositor import Atlas, SolidCanvas, _to_pil, LANCZOS
+from .compositor import open_rgba, Atlas, SolidCanvas, _to_pil, LANCZOS
 
 _P = ctypes.c_void_p
 _MARGIN = 32
@@ -93,7 +93,7 @@ def build_labeled_contact_sheet(objects_dir: str, results_json_path: str,
     cutouts: List[Image.Image] = []
     labels: List[str] = []
     for it in items:
-        cutouts.append(Image.open(str(Path(results_json_path).parent / it["filename"])).convert("RGBA"))
+        cutouts.append(open_rgba(Path(results_json_path).parent / it["filename"]))
         labels.append(str(it.get("label", f"id_{it['object_id']}")))
 
     cell_w, cell_h = int(thumb_size[0]), int(thumb_size[1]) + int(label_height)
