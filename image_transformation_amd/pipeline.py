@@ -26,7 +26,28 @@ from .compositor import SolidCanvas, coerce_placements, composite_device, load_o
 from .contact_sheet import build_labeled_contact_sheet
 from .flex import layout_to_placements
 from .layout_constraints import compute_canvas_size
-from .overlay import save_overlay_debug
+from .overlay import overlay_debug
+
+
+class _PngWriter:
+    """PNG encoding is what is left of the wall time once the pixels come off the GPU (PIL's encoder,
+    ~10 ms per 492x492 artifact, 8 artifacts per run); PIL releases the GIL while it compresses, so the
+    files are written by a small thread pool while the next iteration is placed and composited."""
+
+    def __init__(self, workers: int = 8):
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=workers)
+        self._pending: List[Any] = []
+
+    def save(self, image: Image.Image, path) -> None:
+        self._pending.append(self._pool.submit(image.save, path))
+
+    def close(self) -> None:
+        try:
+            for f in self._pending:
+                f.result()  # re-raise the first I/O error
+        finally:
+            self._pool.shutdown(wait=True)
 
 
 def read_original_size(bundle_dir: Path) -> Tuple[int, int]:
@@ -68,7 +89,18 @@ def run_layouts(bundle_dir: str, ratio: str, flex_layouts: Sequence[Dict[str, An
         if base_out.exists():
             shutil.rmtree(base_out, ignore_errors=True)
         base_out.mkdir(parents=True, exist_ok=True)
+    writer = _PngWriter() if save else None
+    try:
+        return _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, (ow, oh), align, margin, save)
+    finally:
+        if writer is not None:
+            writer.close()
 
+
+def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, original_size, align, margin, save):
+    results_json = bundle / "results.json"
+    bg_path = bundle / "background.png"
+    ow, oh = original_size
     sheet = build_labeled_contact_sheet(str(bundle / "objects"), str(results_json))
     canvas: SolidCanvas = solid_canvas(str(bg_path), canvas_size)
     objects = load_object_images(str(results_json))  # resident atlas on first use
@@ -82,9 +114,9 @@ def run_layouts(bundle_dir: str, ratio: str, flex_layouts: Sequence[Dict[str, An
                 "canvas_size": {"width": canvas_size[0], "height": canvas_size[1]},
                 "original_image": {"width": ow, "height": oh}, "refine_iters": max(0, len(flex_layouts) - 1)}
         (d0["vlm_input_text"] / "run_metadata.json").write_text(json.dumps(meta, indent=2), encoding="utf-8")
-        sheet.save(d0["vlm_input_image"] / "contact_sheet.png")
+        writer.save(sheet, d0["vlm_input_image"] / "contact_sheet.png")
         shutil.copyfile(bg_path, d0["vlm_input_image"] / "background.png")
-        canvas.to_image().save(d0["vlm_input_image"] / "canvas.png")
+        writer.save(canvas.to_image(), d0["vlm_input_image"] / "canvas.png")
 
     drafts: List[Image.Image] = []
     all_placements: List[List[Dict]] = []
@@ -103,9 +135,9 @@ def run_layouts(bundle_dir: str, ratio: str, flex_layouts: Sequence[Dict[str, An
             d = _iter_dirs(base_out, i)
             (d["layout_json"] / f"layout_macro_iter_{i:02d}.json").write_text(json.dumps(final_json, indent=2),
                                                                               encoding="utf-8")
-            draft.save(d["final_product"] / f"draft_macro_iter_{i:02d}.png")
-            save_overlay_debug(final_json["placements"], canvas_size,
-                               d["final_product"] / f"overlay_debug_iter_{i:02d}.png")  # :1514, :1700
+            writer.save(draft, d["final_product"] / f"draft_macro_iter_{i:02d}.png")
+            writer.save(overlay_debug(final_json["placements"], canvas_size),
+                        d["final_product"] / f"overlay_debug_iter_{i:02d}.png")  # :1514, :1700
             (d["layout_json"] / f"provenance_iter_{i:02d}.json").write_text(
                 json.dumps({"method": "flex", "fallback": False, "iteration": i}, indent=2), encoding="utf-8")
     return {"canvas_size": canvas_size, "background_rgba": canvas.rgba, "contact_sheet": sheet, "drafts": drafts,
