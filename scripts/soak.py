@@ -1,0 +1,71 @@
+"""Randomised differential soak: HIP path vs the oracle on many random composites and resizes.
+Not part of the test suite (minutes); run on the GPU box:  python scripts/soak.py [seconds]"""
+import ctypes, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+import numpy as np, torch
+import oracle
+from image_transformation_amd import _native, synthetic
+from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.default_rng(seed)
+ctx = _native.context(); lib = _native.lib(); P = ctypes.c_void_p
+t_end = time.time() + budget
+n_comp = n_rs = 0
+while time.time() < t_end:
+    # ---- a random atlas + a few canvases
+    objs = {i + 1: synthetic.make_cutout(rng, int(rng.integers(1, 260)), int(rng.integers(1, 200)),
+                                         ["binary", "soft"][int(rng.integers(0, 2))]) for i in range(int(rng.integers(1, 9)))}
+    atlas = Atlas(objs)
+    for _ in range(6):
+        W = int(rng.choice([1, 2, 3, 5, 64, 255, 256, 257, 511, 1000, 1023, 1024, 1025, 1366, 2049, 4099]))
+        H = int(rng.integers(1, 80))
+        pl = []
+        for _k in range(int(rng.integers(0, 20))):
+            oid = int(rng.integers(1, len(objs) + 2))
+            sh, sw = objs.get(oid, objs[1]).shape[:2]
+            r = rng.random()
+            if r < 0.25:
+                sw, sh = int(sw * rng.uniform(0.2, 2.5)), int(sh * rng.uniform(0.2, 2.5))
+            elif r < 0.3:
+                sw, sh = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+            x1, y1 = int(rng.integers(-sw - 2, W + 2)), int(rng.integers(-sh - 2, H + 2))
+            pl.append({"object_id": oid, "box": [x1, y1, x1 + sw, y1 + sh]})
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            col = (38, 73, 115, 255)
+        elif kind == 1:
+            col = tuple(int(v) for v in rng.integers(0, 256, 4))
+        if kind < 2:
+            bg_np = np.empty((H, W, 4), np.uint8); bg_np[:] = col
+            canvas = SolidCanvas((W, H), col)
+        else:
+            bg_np = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+            if rng.random() < 0.5: bg_np[:, :, 3] = 255
+            canvas = torch.from_numpy(bg_np).cuda()
+        off = 4 * int(rng.integers(0, 1100))
+        big = torch.zeros(W * H * 4 + 8192, dtype=torch.uint8, device="cuda")
+        out = big[off:off + W * H * 4].view(H, W, 4)
+        filt = int(rng.integers(0, 2))
+        got = composite_device(atlas, [canvas], [coerce_placements(atlas, pl)], outs=[out], filter=filt)[0].cpu().numpy()
+        want = oracle.composite(bg_np, objs, pl, filt)
+        if not np.array_equal(got, want) or big[:off].any() or big[off + W * H * 4:].any():
+            print("COMPOSITE MISMATCH", dict(seed=seed, W=W, H=H, kind=kind, off=off, filt=filt, pl=pl,
+                                             sizes={k: v.shape for k, v in objs.items()}))
+            sys.exit(1)
+        n_comp += 1
+    # ---- a random resize
+    sw, sh = int(rng.integers(1, 700)), int(rng.integers(1, 500))
+    dw, dh = max(1, int(sw * rng.uniform(0.05, 3.0))), max(1, int(sh * rng.uniform(0.05, 3.0)))
+    src = synthetic.make_cutout(rng, sw, sh, ["binary", "soft"][int(rng.integers(0, 2))])
+    dev = torch.from_numpy(src).cuda()
+    dst = torch.empty((dh, dw, 4), dtype=torch.uint8, device="cuda")
+    filt = int(rng.integers(0, 2))
+    _native.check(lib.mic_resize(ctx.handle, P(dev.data_ptr()), sw, sh, P(dst.data_ptr()), dw, dh, filt, P(ctx.stream_ptr())))
+    if not np.array_equal(dst.cpu().numpy(), oracle.resize(src, (dw, dh), filt)):
+        print("RESIZE MISMATCH", dict(seed=seed, src=(sw, sh), dst=(dw, dh), filt=filt))
+        sys.exit(1)
+    n_rs += 1
+print(f"soak ok: {n_comp} composites, {n_rs} resizes, seed {seed}, {budget:.0f} s")
