@@ -208,8 +208,9 @@ __device__ __forceinline__ int combine(int a0, int a1, int a2) {
 // EDGE: C is not a multiple of 4 (only when the window ends at the image's right edge): the last
 // group of each row is re-read pixel by pixel.
 template <bool EDGE>
-__device__ __forceinline__ void load_window(gcptr src, int sw, int last4, int origin, int R, int C, uint8_t *srcP,
-                                            int pitch_c, int plane_s, int tid) {
+__device__ __forceinline__ uint32_t load_window(gcptr src, int sw, int last4, int origin, int R, int C, uint8_t *srcP,
+                                                int pitch_c, int plane_s, int tid) {
+    uint32_t seen = 0;  // OR of the pixels this thread handled: bits 24-31 say whether any had alpha > 0
     const int G = (C + 3) >> 2;
     const int dq = 256 / G, dr = 256 - dq * G;
     int rr = tid / G, g = tid - rr * G;
@@ -238,6 +239,7 @@ __device__ __forceinline__ void load_window(gcptr src, int sw, int last4, int or
                 px[2] = left > 2 ? src[igi[k] + 2] : 0u;
                 px[3] = 0u;
             }
+            seen |= px[0] | px[1] | px[2] | px[3];
             uint32_t rb[4], ga[4];  // premultiplied {R, B} and {G, A} in bytes 1 and 3
             // Cutouts are mostly binary-alpha (the reference's bundles have no partial alpha at all):
             // when every pixel this wave holds has alpha 0 or 255, premultiplying is a select.
@@ -271,6 +273,7 @@ __device__ __forceinline__ void load_window(gcptr src, int sw, int last4, int or
             dst[3 * (plane_s >> 2)] = byte_perm(ga23, ga01, 0x07060302u) ^ 0x80808080u;  // A
         }
     }
+    return seen;
 }
 
 // One 16 x 16 output tile: acc[channel][digit] = bias + sum over the window's 64-sample chunks of
@@ -349,13 +352,23 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__rest
     recip[tid] = unpremul_factor((uint32_t)tid);
 
     // ---- 1. source window -> premultiplied signed-byte planes
+    uint32_t seen;
     if ((C & 3) == 0)
-        load_window<false>(reinterpret_cast<gcptr>(J.src), J.sw, J.sw * J.sh - 4, r_lo * J.sw + c_lo, R, C, srcP,
-                           J.pitch_c, plane_s, tid);
+        seen = load_window<false>(reinterpret_cast<gcptr>(J.src), J.sw, J.sw * J.sh - 4, r_lo * J.sw + c_lo, R, C, srcP,
+                                  J.pitch_c, plane_s, tid);
     else  // the window ends at the image's right edge in the middle of a group of 4 columns
-        load_window<true>(reinterpret_cast<gcptr>(J.src), J.sw, J.sw * J.sh - 4, r_lo * J.sw + c_lo, R, C, srcP,
-                          J.pitch_c, plane_s, tid);
-    __syncthreads();
+        seen = load_window<true>(reinterpret_cast<gcptr>(J.src), J.sw, J.sw * J.sh - 4, r_lo * J.sw + c_lo, R, C, srcP,
+                                 J.pitch_c, plane_s, tid);
+    // A window without a single pixel of alpha > 0 (the corners around a cutout's shape) premultiplies
+    // to all zeros, and both passes of zeros give clip8(2^21 >> 22) = 0: the tile is transparent black.
+    if (!__syncthreads_or((seen >> 24) != 0u)) {
+        gptr dst = reinterpret_cast<gptr>(J.dst);
+        const int ox0 = xt0 * 16, oy0 = yt0 * 16;
+        const int tw = min(16 * n_xt, J.dw - ox0), th = min(16 * n_yt, J.dh - oy0);
+        for (int yy = wave; yy < th; yy += 4)
+            for (int xx = lane; xx < tw; xx += 64) dst[(uint32_t)((oy0 + yy) * J.dw + ox0 + xx)] = 0u;
+        return;
+    }
 
     // ---- 2. horizontal pass: window rows -> 8-bit intermediate, transposed.  A wave keeps one
     // x-tile (its tap fragments stay in registers) and walks the row tiles two at a time: the second
