@@ -326,6 +326,7 @@ __device__ __forceinline__ void store_pixels(const uint32_t (&w)[4], gptr dst, i
         if (ox < dw && oy + r < dh) dst[(uint32_t)((oy + r) * dw + ox)] = unpremultiply_with(px[r], recip);  // < 2^31 px
 }
 
+template <bool BANDED>
 __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__restrict__ jobs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
     const RsMfma J = jobs[blockIdx.y];
@@ -351,40 +352,54 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__rest
     __shared__ float recip[256];                    // unpremultiply factors 255/a: an LDS read per pixel
     recip[tid] = unpremul_factor((uint32_t)tid);
 
-    // ---- 1. source window -> premultiplied signed-byte planes
-    uint32_t seen;
-    if ((C & 3) == 0)
-        seen = load_window<false>(reinterpret_cast<gcptr>(J.src), J.sw, J.sw * J.sh - 4, r_lo * J.sw + c_lo, R, C, srcP,
-                                  J.pitch_c, plane_s, tid);
-    else  // the window ends at the image's right edge in the middle of a group of 4 columns
-        seen = load_window<true>(reinterpret_cast<gcptr>(J.src), J.sw, J.sw * J.sh - 4, r_lo * J.sw + c_lo, R, C, srcP,
-                                 J.pitch_c, plane_s, tid);
-    // A window without a single pixel of alpha > 0 (the corners around a cutout's shape) premultiplies
-    // to all zeros, and both passes of zeros give clip8(2^21 >> 22) = 0: the tile is transparent black.
-    if (!__syncthreads_or((seen >> 24) != 0u)) {
-        gptr dst = reinterpret_cast<gptr>(J.dst);
-        const int ox0 = xt0 * 16, oy0 = yt0 * 16;
-        const int tw = min(16 * n_xt, J.dw - ox0), th = min(16 * n_yt, J.dh - oy0);
-        for (int yy = wave; yy < th; yy += 4)
-            for (int xx = lane; xx < tw; xx += 64) dst[(uint32_t)((oy0 + yy) * J.dw + ox0 + xx)] = 0u;
-        return;
-    }
+    // ---- 1 + 2, per band of J.rows16 window rows (all of them at once unless the window is too tall
+    // for LDS -- deep shrinks -- in which case the source planes hold one band at a time and only the
+    // 8-bit intermediate covers the whole window).
+    // (Two instantiations: the banded loop keeps the loader's and the pass's registers alive together
+    // -- 192 VGPRs, two waves per SIMD -- which the common whole-window case must not pay for.)
+    int band0 = 0;
+    do {
+        const int Rb = BANDED ? min(J.rows16, R - band0) : R;
+        if (BANDED && band0 > 0) __syncthreads();  // the previous band's horizontal pass is done reading srcP
 
-    // ---- 2. horizontal pass: window rows -> 8-bit intermediate, transposed.  A wave keeps one
-    // x-tile (its tap fragments stay in registers) and walks the row tiles two at a time: the second
-    // tile's MFMAs run in the matrix pipe while the VALU does the first tile's epilogue.
-    {
+        // ---- 1. source rows -> premultiplied signed-byte planes
+        uint32_t seen;
+        if ((C & 3) == 0)
+            seen = load_window<false>(reinterpret_cast<gcptr>(J.src), J.sw, J.sw * J.sh - 4, (r_lo + band0) * J.sw + c_lo,
+                                      Rb, C, srcP, J.pitch_c, plane_s, tid);
+        else  // the window ends at the image's right edge in the middle of a group of 4 columns
+            seen = load_window<true>(reinterpret_cast<gcptr>(J.src), J.sw, J.sw * J.sh - 4, (r_lo + band0) * J.sw + c_lo,
+                                     Rb, C, srcP, J.pitch_c, plane_s, tid);
+        if (!BANDED) {
+            // A window without a single pixel of alpha > 0 (the corners around a cutout's shape)
+            // premultiplies to all zeros, and both passes of zeros give clip8(2^21 >> 22) = 0: the tile is
+            // transparent black.
+            if (!__syncthreads_or((seen >> 24) != 0u)) {
+                gptr dst = reinterpret_cast<gptr>(J.dst);
+                const int ox0 = xt0 * 16, oy0 = yt0 * 16;
+                const int tw = min(16 * n_xt, J.dw - ox0), th = min(16 * n_yt, J.dh - oy0);
+                for (int yy = wave; yy < th; yy += 4)
+                    for (int xx = lane; xx < tw; xx += 64) dst[(uint32_t)((oy0 + yy) * J.dw + ox0 + xx)] = 0u;
+                return;
+            }
+        } else {
+            __syncthreads();
+        }
+
+        // ---- 2. horizontal pass: window rows -> 8-bit intermediate, transposed.  A wave keeps one
+        // x-tile (its tap fragments stay in registers) and walks the row tiles two at a time: the second
+        // tile's MFMAs run in the matrix pipe while the VALU does the first tile's epilogue.
         const int groups = 4 / n_xt;  // waves per x-tile (n_xt <= 4)
         if (wave < n_xt * groups) {
             const int xi = wave % n_xt, sub = wave / n_xt;
-            const int n_rt = (R + 15) >> 4;
+            const int n_rt = (Rb + 15) >> 4;
             const v4i m = hmeta[xt0 + xi];
             const int b = reinterpret_cast<gciptr>(J.hbias)[(xt0 + xi) * 16 + l15];
             const v4i bias = {b, b, b, b};
             gv4ptr fbase = reinterpret_cast<gv4ptr>(J.hfrag) + (size_t)m[2] * 3 * 64 + lane;
             const v4i f[3] = {fbase[0], fbase[64], fbase[128]};
             const uint8_t *a0 = srcP + l15 * J.pitch_c + (m[0] - c_lo) + 16 * lh;      // + 16 rt pitch_c
-            uint8_t *m0 = midT + (xi * 16 + l15) * J.pitch_r + 4 * lh;                 // + 16 rt
+            uint8_t *m0 = midT + (xi * 16 + l15) * J.pitch_r + band0 + 4 * lh;         // + 16 rt
             for (int rt = sub; rt < n_rt; rt += 2 * groups) {
                 const int rt2 = rt + groups;
                 const bool two = rt2 < n_rt;  // wave-uniform
@@ -404,7 +419,8 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__rest
                 }
             }
         }
-    }
+        band0 += J.rows16;
+    } while (BANDED && band0 < R);
     __syncthreads();
 
     // ---- 3. vertical pass + unpremultiply + store: a wave keeps one y-tile, walks the x-tiles
@@ -438,24 +454,33 @@ __global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__rest
     }
 }
 
-hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int max_tiles, size_t lds_bytes,
+// jobs_dev[0, n_whole) keep their whole source window in LDS, jobs_dev[n_whole, n_jobs) are banded.
+hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes,
                                 hipStream_t stream) {
-    if (n_jobs <= 0 || max_tiles <= 0) return hipSuccess;
-    // opt the kernel in for more than 64 KB of dynamic LDS, once per device of this process
+    if (n_jobs <= 0) return hipSuccess;
+    // opt the kernels in for more than 64 KB of dynamic LDS, once per device of this process
     static bool attr_set[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_mfma_kernel),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_mfma_kernel<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsMfmaMaxLds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_mfma_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsMfmaMaxLds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
-    for (int first = 0; first < n_jobs; first += 65535) {  // grid.y limit
+    for (int first = 0; first < n_whole; first += 65535) {  // grid.y limit
+        const int n = std::min(65535, n_whole - first);
+        hipLaunchKernelGGL(resample_mfma_kernel<false>, dim3((unsigned)kRsTilesPerEntry, (unsigned)n), dim3(256),
+                           lds_bytes, stream, jobs_dev + first);
+    }
+    for (int first = n_whole; first < n_jobs; first += 65535) {
         const int n = std::min(65535, n_jobs - first);
-        hipLaunchKernelGGL(resample_mfma_kernel, dim3((unsigned)kRsTilesPerEntry, (unsigned)n), dim3(256), lds_bytes,
-                           stream, jobs_dev + first);
+        hipLaunchKernelGGL(resample_mfma_kernel<true>, dim3((unsigned)kRsTilesPerEntry, (unsigned)n), dim3(256),
+                           lds_bytes, stream, jobs_dev + first);
     }
     return hipGetLastError();
 }

@@ -472,6 +472,7 @@ struct ResizePlan {
 struct PassTables {
     std::vector<RsMfma> fused;
     int fused_layers = 0;
+    int fused_whole = 0;  // entries [0, fused_whole) keep their whole window in LDS, the rest are banded
     int fused_max_tiles = 0;
     size_t fused_lds = 0;
     std::vector<RsJob> h, v;
@@ -506,19 +507,28 @@ int choose_fused(mic_ctx *ctx, ResizePlan *p, int filter) {
     static const int kTiles[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
     p->tx16 = 0;
     if ((int64_t)p->sw * p->sh < 4) return MIC_OK;  // the kernel's 16-byte loads need 4 pixels to clamp into
-    for (const size_t cap : {kRsMfmaPreferredLds, kRsMfmaMaxLds}) {
-        for (const auto &t : kTiles) {
-            int tc, nc, tr, nr;
-            window_extents(*fh.meta_host, fh.tiles, t[0], &tc, &nc);
-            window_extents(*fv.meta_host, fv.tiles, t[1], &tr, &nr);
-            // Pitches cover what a tile needs, not what its 64-sample chunks touch: a read past the
-            // end of a row lands in the next row (or in the 64 bytes of slack after the last one)
-            // and meets zero tap digits.
-            (void)tc; (void)tr;
-            const int pitch_c = round16(nc), rows16 = round16(nr), pitch_r = rows16;
-            if (rs_mfma_lds_bytes(rows16, pitch_c, t[0], pitch_r) <= cap) {
-                p->tx16 = t[0]; p->ty16 = t[1]; p->pitch_c = pitch_c; p->pitch_r = pitch_r; p->rows16 = rows16;
-                return MIC_OK;
+    // Whole window resident first (preferred LDS size, then anything that fits); only windows too tall
+    // for that (deep shrinks) get source planes that hold one band of rows at a time.  Those have few
+    // output tiles, so the banded candidates go from the smallest tile up (more workgroups), with
+    // enough row tiles per band to keep the four waves busy.
+    for (const bool banded : {false, true}) {
+        for (const size_t cap : {kRsMfmaPreferredLds, kRsMfmaMaxLds}) {
+            for (int ti = 0; ti < 5; ++ti) {
+                const auto &t = kTiles[banded ? 4 - ti : ti];
+                int tc, nc, tr, nr;
+                window_extents(*fh.meta_host, fh.tiles, t[0], &tc, &nc);
+                window_extents(*fv.meta_host, fv.tiles, t[1], &tr, &nr);
+                // Pitches cover what a tile needs, not what its 64-sample chunks touch: a read past the
+                // end of a row lands in the next row (or in the 64 bytes of slack after the last one)
+                // and meets zero tap digits.
+                (void)tc; (void)tr;
+                const int pitch_c = round16(nc), pitch_r = round16(nr);
+                const int rows16 = banded ? std::min(pitch_r, std::max(16, 64 / t[0])) : pitch_r;
+                if (banded && rows16 == pitch_r) continue;  // same as the unbanded candidate
+                if (rs_mfma_lds_bytes(rows16, pitch_c, t[0], pitch_r) <= cap) {
+                    p->tx16 = t[0]; p->ty16 = t[1]; p->pitch_c = pitch_c; p->pitch_r = pitch_r; p->rows16 = rows16;
+                    return MIC_OK;
+                }
             }
         }
     }
@@ -585,6 +595,9 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             pt->max_v_out_h = std::max(pt->max_v_out_h, p.dh);
         }
     }
+    // whole-window entries first, banded ones after (two kernel instantiations, launch_resample_mfma)
+    auto whole = [](const RsMfma &f) { return f.rows16 >= f.pitch_r; };
+    pt->fused_whole = (int)(std::stable_partition(pt->fused.begin(), pt->fused.end(), whole) - pt->fused.begin());
     return MIC_OK;
 }
 
@@ -871,7 +884,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], stream));
     HIP_TRY(launch_resample_mfma(reinterpret_cast<const RsMfma *>(dp + P->off_f), (int)P->pt.fused.size(),
-                                  P->pt.fused_max_tiles, P->pt.fused_lds, stream));
+                                  P->pt.fused_whole, P->pt.fused_lds, stream));
     HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + P->off_h), (int)P->pt.h.size(),
                               P->pt.max_h_out_w, P->pt.max_h_rows, stream));
     HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + P->off_v), (int)P->pt.v.size(),
@@ -1063,7 +1076,7 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
     slot->pending = true;
     char *dp = static_cast<char *>(slot->dev);
     HIP_TRY(launch_resample_mfma(reinterpret_cast<const RsMfma *>(dp + off_f), (int)pt.fused.size(),
-                                  pt.fused_max_tiles, pt.fused_lds, stream));
+                                  pt.fused_whole, pt.fused_lds, stream));
     HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp), (int)pt.h.size(), pt.max_h_out_w,
                               pt.max_h_rows, stream));
     HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + off_v), (int)pt.v.size(), pt.max_v_out_w,

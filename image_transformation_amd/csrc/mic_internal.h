@@ -82,7 +82,8 @@ struct alignas(16) RsMfma {
     int32_t tx16, ty16;            // workgroup tile in units of 16 output samples
     int32_t tiles_x, tiles_y;
     int32_t pitch_c, pitch_r;      // bytes per row of a source plane / per column of an intermediate plane
-    int32_t rows16;                // rows of a source plane (multiple of 16)
+    int32_t rows16;                // rows of a source plane (multiple of 16): the whole window of a tile, or
+                                   // one band of it when the window is too tall for LDS (deep shrinks)
     // A layer with more than kRsTilesPerEntry tiles takes several table entries (grid.y); workgroup
     // bx of entry e works on tile ((bx + xcd_rot) & 7) * 4 n_entries + 4 e + (bx >> 3): workgroups
     // are dealt round-robin over the 8 XCDs, so each XCD gets a contiguous band of the layer's tiles
@@ -110,7 +111,7 @@ hipError_t launch_resample_h(const RsJob *jobs_dev, int n_jobs, int max_out_w, i
                              hipStream_t stream);
 hipError_t launch_resample_v(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_out_h,
                              hipStream_t stream);
-hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int max_tiles, size_t lds_bytes,
+hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes,
                                 hipStream_t stream);
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);
 hipError_t launch_gradient(void *out, int W, int H, const uint8_t c1[3], const uint8_t c2[3], int vertical,
