@@ -43,7 +43,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *mic_last_error(void) { return g_err; }
-extern "C" int mic_version(void) { return (1 << 16) | 0; }
+extern "C" int mic_version(void) { return (1 << 16) | 3; }  // 1.3: + mic_render, mic_draw_rect_outlines, mic_profile_begin_sampled
 
 // ------------------------------------------------------------------------------------ blob layout
 namespace {
