@@ -14,7 +14,11 @@ rng = np.random.default_rng(seed)
 ctx = _native.context(); lib = _native.lib(); P = ctypes.c_void_p
 t_end = time.time() + budget
 n_comp = n_rs = 0
+t_say = time.time() + 30
 while time.time() < t_end:
+    if time.time() > t_say:  # progress line: long silent GPU runs are taken for hung
+        print(f"... {n_comp} composites, {n_rs} resizes so far", flush=True)
+        t_say = time.time() + 30
     # ---- a random atlas + a few canvases
     objs = {i + 1: synthetic.make_cutout(rng, int(rng.integers(1, 260)), int(rng.integers(1, 200)),
                                          ["binary", "soft"][int(rng.integers(0, 2))]) for i in range(int(rng.integers(1, 9)))}
