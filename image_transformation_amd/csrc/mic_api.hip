@@ -507,6 +507,7 @@ int choose_fused(mic_ctx *ctx, ResizePlan *p, int filter) {
     static const int kTiles[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
     p->tx16 = 0;
     if ((int64_t)p->sw * p->sh < 4) return MIC_OK;  // the kernel's 16-byte loads need 4 pixels to clamp into
+    if ((int64_t)p->sw * p->sh >= ((int64_t)1 << 30)) return MIC_OK;  // its 32-bit pixel index steps past the end
     // Whole window resident first (preferred LDS size, then anything that fits); only windows too tall
     // for that (deep shrinks) get source planes that hold one band of rows at a time.  Those have few
     // output tiles, so the banded candidates go from the smallest tile up (more workgroups), with
@@ -1046,6 +1047,11 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
     if (src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0 || src_w > kMaxDim || src_h > kMaxDim ||
         dst_w > kMaxDim || dst_h > kMaxDim)
         return fail(MIC_ERR_INVALID, "mic_resize: invalid size %dx%d -> %dx%d", src_w, src_h, dst_w, dst_h);
+    // the kernels index pixels with 32 bits (also across the two-pass fallback's dst_w x src_h intermediate)
+    if ((int64_t)src_w * src_h >= ((int64_t)1 << 31) || (int64_t)dst_w * dst_h >= ((int64_t)1 << 31) ||
+        (int64_t)dst_w * src_h >= ((int64_t)1 << 31))
+        return fail(MIC_ERR_INVALID, "mic_resize: images of 2^31 pixels or more are not supported (%dx%d -> %dx%d)",
+                    src_w, src_h, dst_w, dst_h);
     if (filter != MIC_FILTER_LANCZOS && filter != MIC_FILTER_BILINEAR)
         return fail(MIC_ERR_INVALID, "unknown filter %d", filter);
     if (int rc = adopt_stream(ctx, stream)) return rc;
