@@ -309,9 +309,16 @@ def main():
         torch.cuda.synchronize()
         e2 = time.perf_counter() - t0
         n2, c2, r2 = ctx.profile_end()
+        ps = pplan.stats()
+        rs_bytes = 4 * (ps["source_pixels"] + sum(max(1, p["box"][2] - p["box"][0]) * max(1, p["box"][3] - p["box"][1])
+                                                  for p in ppl))  # every cutout read once + every resampled pixel written once
         result["placements_mode_lanczos"] = {"ms_per_canvas_wall": round(e2 / 10 * 1e3, 3),
                                              "resample_ms": round(r2 / n2, 3), "composite_ms": round(c2 / n2, 4),
-                                             "Mpixels_per_s": round(W * H * 10 / e2 / 1e6, 1)}
+                                             "Mpixels_per_s": round(W * H * 10 / e2 / 1e6, 1),
+                                             "resample_roofline": {"bound": "valu (instruction issue), not hbm",
+                                                                   "algorithmic_bytes": rs_bytes,
+                                                                   "achieved_GBps": round(rs_bytes / (r2 / n2 * 1e-3) / 1e9, 1),
+                                                                   "frac_of_hbm_peak": round(rs_bytes / (r2 / n2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
 
         # PCIe-inclusive step: job-table upload + composite + D2H of every canvas into pinned memory
         # (SURVEY 8d's end-to-end figure; never `value`)
