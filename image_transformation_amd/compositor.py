@@ -73,6 +73,25 @@ def _image_to_array(img: Image.Image) -> np.ndarray:
     return np.asarray(img, dtype=np.uint8)
 
 
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def _device_guard(ctx: _native.Context):
+    """libmic sets the HIP device of the calling thread to its context's; keep torch's notion of the
+    current device intact when that is another one (one process driving several GPUs), and skip the
+    several-microsecond guard in the usual one-process-per-GPU case."""
+    torch = _torch()
+    return _NO_GUARD if torch.cuda.current_device() == ctx.device else torch.cuda.device(ctx.torch_device)
+
+
 class _Pinned:
     """Per-process pinned host buffers for the PIL-level entry points: a pageable 33 MB transfer is
     staged by the runtime at a few GB/s, a pinned one moves at PCIe speed.  One buffer per direction,
@@ -469,7 +488,7 @@ def composite_device(atlas: Atlas, canvases: Sequence[Union[SolidCanvas, Any]],
             raise ValueError("output canvas has the wrong shape/dtype/device")
         jobs[i].out_dev = out.data_ptr()
     atl = (_P * 1)(atlas.handle)
-    with torch.cuda.device(ctx.torch_device):
+    with _device_guard(ctx):
         _native.check(_native.lib().mic_composite_batch(ctx.handle, 1, atl, len(sizes), jobs, filter,
                                                         _P(ctx.stream_ptr())))
     del keep
@@ -531,7 +550,7 @@ def _render_native(layout_json: Any, atlas: "Atlas", canvas: Any, size: Tuple[in
             raise ValueError("canvas lives on another device than the atlas")
         bg_ptr, rgba = canvas.data_ptr(), (ctypes.c_uint8 * 4)(0, 0, 0, 0)
     out = torch.empty((H, W, 4), dtype=torch.uint8, device=ctx.torch_device)
-    with torch.cuda.device(ctx.torch_device):
+    with _device_guard(ctx):
         rc = _native.lib().mic_render(ctx.handle, atlas.handle, text, len(text), W, H, _P(bg_ptr) if bg_ptr else None,
                                       rgba, filter, _P(out.data_ptr()), _P(ctx.stream_ptr()), None)
     if rc in (_native.ERR_UNSUPPORTED, _native.ERR_FORMAT):
