@@ -149,6 +149,10 @@ struct mic_atlas {
     uint64_t uid = 0;
     std::vector<BlobEntry> entries;
     std::unordered_map<int32_t, int> index;
+    // resident planar premultiplied copy of every cutout (built by the first resample that needs it)
+    mutable void *planar = nullptr;             // (a cache: filled through const atlases)
+    mutable std::vector<uint64_t> planar_off;   // per entry, bytes from `planar`
+    mutable std::vector<int32_t> planar_pitch;
 };
 
 static int ctx_enter(mic_ctx *ctx) {
@@ -446,12 +450,55 @@ extern "C" int mic_atlas_lookup(const mic_atlas *atlas, int32_t id, int32_t *wid
 
 extern "C" int mic_atlas_destroy(mic_atlas *atlas) {
     if (!atlas) return MIC_OK;
-    if (atlas->owns && atlas->blob) {
+    if ((atlas->owns && atlas->blob) || atlas->planar) {
         (void)hipSetDevice(atlas->ctx->device);
         (void)hipDeviceSynchronize();
-        (void)hipFree(atlas->blob);
+        if (atlas->owns && atlas->blob) (void)hipFree(atlas->blob);
+        if (atlas->planar) (void)hipFree(atlas->planar);
     }
     delete atlas;
+    return MIC_OK;
+}
+
+// The atlas' planar premultiplied copy (kernels_resample.hip: planarize_kernel), built once, on the
+// default stream, and waited for: every later launch on any stream sees it.
+static int atlas_ensure_planar(const mic_atlas *A) {
+    if (A->planar || A->entries.empty()) return MIC_OK;
+    const size_t n = A->entries.size();
+    std::vector<PlanarJob> jobs(n);
+    A->planar_off.assign(n, 0);
+    A->planar_pitch.assign(n, 0);
+    size_t total = 0;
+    int64_t max_items = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const BlobEntry &e = A->entries[i];
+        const int pitch = (e.w + 15) / 16 * 16;
+        A->planar_off[i] = total;
+        A->planar_pitch[i] = pitch;
+        total = align_up(total + (size_t)4 * e.h * pitch, 256);
+        max_items = std::max<int64_t>(max_items, (int64_t)(pitch / 4) * e.h);
+    }
+    void *buf = nullptr, *jobs_dev = nullptr;
+    HIP_TRY(hipMalloc(&buf, total));
+    hipError_t e = hipMalloc(&jobs_dev, sizeof(PlanarJob) * n);
+    if (e == hipSuccess) {
+        for (size_t i = 0; i < n; ++i) {
+            jobs[i].src = reinterpret_cast<uint64_t>(A->blob) + A->entries[i].offset;
+            jobs[i].dst = reinterpret_cast<uint64_t>(buf) + A->planar_off[i];
+            jobs[i].w = A->entries[i].w; jobs[i].h = A->entries[i].h; jobs[i].pitch = A->planar_pitch[i];
+        }
+        e = hipMemcpy(jobs_dev, jobs.data(), sizeof(PlanarJob) * n, hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = launch_planarize(static_cast<const PlanarJob *>(jobs_dev), (int)n, max_items, nullptr);
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+    if (jobs_dev) (void)hipFree(jobs_dev);
+    if (e != hipSuccess) {
+        (void)hipFree(buf);
+        A->planar_off.clear();
+        A->planar_pitch.clear();
+        return fail(MIC_ERR_HIP, "building the atlas' planar copy: %s", hipGetErrorString(e));
+    }
+    A->planar = buf;
     return MIC_OK;
 }
 
@@ -467,6 +514,8 @@ struct ResizePlan {
     uint64_t dst_ptr = 0; // caller-provided destination (mic_resize)
     // MFMA kernel (source planes + 8-bit intermediate in LDS); tx16 == 0: two-pass fallback
     int tx16 = 0, ty16 = 0, pitch_c = 0, pitch_r = 0, rows16 = 0;
+    uint64_t planar_src = 0;  // the cutout in its atlas' planar premultiplied copy (0: none, e.g. mic_resize)
+    int planar_pitch = 0;
 };
 
 struct PassTables {
@@ -546,7 +595,8 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             if (int rc = get_frags(ctx, p.sw, p.dw, filter, &fh)) return rc;
             if (int rc = get_frags(ctx, p.sh, p.dh, filter, &fv)) return rc;
             RsMfma f{};
-            f.src = p.src; f.dst = dst;
+            f.src = p.planar_src ? p.planar_src : p.src; f.dst = dst;
+            f.planar_pitch = p.planar_src ? p.planar_pitch : 0;
             f.hmeta = fh.meta; f.hbias = fh.bias; f.hfrag = fh.frags;
             f.vmeta = fv.meta; f.vbias = fv.bias; f.vfrag = fv.frags;
             f.sw = p.sw; f.sh = p.sh; f.dw = p.dw; f.dh = p.dh;
@@ -725,6 +775,11 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                     rp.src = reinterpret_cast<uint64_t>(A->blob) + E.offset;
                     rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
                     if (int rc = choose_fused(ctx, &rp, filter)) return rc;
+                    if (rp.tx16 > 0) {
+                        if (int rc = atlas_ensure_planar(A)) return rc;
+                        rp.planar_src = reinterpret_cast<uint64_t>(A->planar) + A->planar_off[(size_t)it->second];
+                        rp.planar_pitch = A->planar_pitch[(size_t)it->second];
+                    }
                     if (rp.tx16 == 0 && rp.dw != rp.sw && rp.dh != rp.sh) {
                         rp.tmp_off = scratch_need;
                         scratch_need = align_up(scratch_need + (size_t)rp.dw * rp.sh * 4 + kGuard, kPixelAlign);

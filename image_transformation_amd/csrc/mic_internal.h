@@ -89,7 +89,10 @@ struct alignas(16) RsMfma {
     // are dealt round-robin over the 8 XCDs, so each XCD gets a contiguous band of the layer's tiles
     // and neighbouring tiles (which share their source halo) share an L2.
     int32_t entry, n_entries, xcd_rot;
-    int32_t pad[2];
+    // > 0: `src` is the atlas' planar premultiplied copy of the cutout (four planes of sh rows, this many
+    // bytes per row); 0: `src` is interleaved RGBA and is premultiplied while it is loaded.
+    int32_t planar_pitch;
+    int32_t pad;
 };
 static_assert(sizeof(RsMfma) == 128, "RsMfma layout");
 inline size_t rs_mfma_lds_bytes(int rows16, int pitch_c, int tx16, int pitch_r) {
@@ -111,6 +114,14 @@ hipError_t launch_resample_h(const RsJob *jobs_dev, int n_jobs, int max_out_w, i
                              hipStream_t stream);
 hipError_t launch_resample_v(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_out_h,
                              hipStream_t stream);
+// One cutout of an atlas to premultiply + planarise (kernels_resample.hip: planarize_kernel).
+struct alignas(16) PlanarJob {
+    uint64_t src;  // interleaved RGBA, w x h
+    uint64_t dst;  // 4 planes of h rows x pitch bytes
+    int32_t w, h, pitch, pad;
+};
+static_assert(sizeof(PlanarJob) == 32, "PlanarJob layout");
+hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream);
 hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes,
                                 hipStream_t stream);
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);
