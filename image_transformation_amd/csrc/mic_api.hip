@@ -150,6 +150,7 @@ struct mic_atlas {
     std::vector<BlobEntry> entries;
     std::unordered_map<int32_t, int> index;
     // resident planar premultiplied copy of every cutout (built by the first resample that needs it)
+    mutable int resample_calls = 0;             // composite calls that resampled cutouts of this atlas
     mutable void *planar = nullptr;             // (a cache: filled through const atlases)
     mutable std::vector<uint64_t> planar_off;   // per entry, bytes from `planar`
     mutable std::vector<int32_t> planar_pitch;
@@ -717,6 +718,7 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
     std::vector<Pending> pending;  // layers whose src is a scratch offset, patched once scratch exists
     std::map<std::tuple<uint64_t, int, int, int>, size_t> dedup;  // (atlas uid, entry, w, h) -> plan
     size_t scratch_need = kPixelAlign;  // leading guard band
+    std::vector<bool> resampled_atlas((size_t)std::max(n_atlases, 1), false);  // atlases this call resamples from
 
     for (int ji = 0; ji < n_jobs; ++ji) {
         const mic_job &J = jobs[ji];
@@ -776,9 +778,17 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                     rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
                     if (int rc = choose_fused(ctx, &rp, filter)) return rc;
                     if (rp.tx16 > 0) {
-                        if (int rc = atlas_ensure_planar(A)) return rc;
-                        rp.planar_src = reinterpret_cast<uint64_t>(A->planar) + A->planar_off[(size_t)it->second];
-                        rp.planar_pitch = A->planar_pitch[(size_t)it->second];
+                        // The planar copy pays for itself from the second resampling call on: an atlas
+                        // made for one call (composite() on a plain dict, a contact sheet) never builds it.
+                        if (!resampled_atlas[(size_t)Pl.atlas]) {
+                            resampled_atlas[(size_t)Pl.atlas] = true;
+                            if (!A->planar && (A->resample_calls++ >= 1 || persistent))  // a plan is made to be re-run
+                                if (int rc = atlas_ensure_planar(A)) return rc;
+                        }
+                        if (A->planar) {
+                            rp.planar_src = reinterpret_cast<uint64_t>(A->planar) + A->planar_off[(size_t)it->second];
+                            rp.planar_pitch = A->planar_pitch[(size_t)it->second];
+                        }
                     }
                     if (rp.tx16 == 0 && rp.dw != rp.sw && rp.dh != rp.sh) {
                         rp.tmp_off = scratch_need;
