@@ -131,6 +131,7 @@ struct mic_ctx {
     std::map<CoefKey, CoefEntry> coefs;
     std::map<CoefKey, FragEntry> frags;  // key.transposed unused (0)
     uint32_t *median_scratch = nullptr;  // device: histogram words + 1 result word
+    uint32_t *gradient_table = nullptr;  // device: fill_gradient's per-position colours (allocated on first use)
     uint32_t *median_host = nullptr;     // pinned
     hipStream_t last_stream = nullptr;
     mic_stats stats{};
@@ -218,6 +219,7 @@ extern "C" int mic_destroy(mic_ctx *ctx) {
     for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->median_scratch) (void)hipFree(ctx->median_scratch);
+    if (ctx->gradient_table) (void)hipFree(ctx->gradient_table);
     if (ctx->median_host) (void)hipHostFree(ctx->median_host);
     delete ctx;
     return MIC_OK;
@@ -1198,7 +1200,11 @@ extern "C" int mic_fill_gradient(mic_ctx *ctx, void *out_dev, int32_t width, int
     if (int rc = ctx_enter(ctx)) return rc;
     if (!out_dev || !c1 || !c2 || width <= 0 || height <= 0 || width > kMaxDim || height > kMaxDim)
         return fail(MIC_ERR_INVALID, "mic_fill_gradient: bad arguments");
-    HIP_TRY(launch_gradient(out_dev, width, height, c1, c2, vertical ? 1 : 0, static_cast<hipStream_t>(stream_v)));
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (int rc = adopt_stream(ctx, stream)) return rc;  // the table is context scratch: one stream at a time
+    if (!ctx->gradient_table)
+        HIP_TRY(hipMalloc(reinterpret_cast<void **>(&ctx->gradient_table), kGradientTableWords * sizeof(uint32_t)));
+    HIP_TRY(launch_gradient(out_dev, width, height, c1, c2, vertical ? 1 : 0, ctx->gradient_table, stream));
     return MIC_OK;
 }
 

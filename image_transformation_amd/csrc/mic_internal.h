@@ -125,8 +125,10 @@ hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_i
 hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes,
                                 hipStream_t stream);
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);
+// table_dev: scratch for max(W, H) <= 65535 colours (kGradientTableWords uint32)
 hipError_t launch_gradient(void *out, int W, int H, const uint8_t c1[3], const uint8_t c2[3], int vertical,
-                           hipStream_t stream);
+                           uint32_t *table_dev, hipStream_t stream);
+constexpr size_t kGradientTableWords = 65536;
 // One rectangle outline of the debug overlay (kernels_overlay.hip), resolved on the host.
 struct alignas(16) OutlineRect {
     int32_t x0, y0, x1, y1;  // ImageDraw.rectangle's box, inclusive
