@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <new>
@@ -114,12 +115,23 @@ struct CoefEntry {
     int32_t *coeffs = nullptr;  // device
 };
 // One axis in the MFMA kernel's fragment form (resample_coeffs.h AxisFrags), one device allocation.
+// Device buffer of one axis' fragment tables.  Ref-counted: the context's cache holds one reference,
+// every plan whose tables point into the buffer another, so the cache can drop old entries (a service
+// that keeps meeting new sizes) without pulling memory from under a persistent plan.
+struct FragBuffer {
+    void *dev = nullptr;
+    size_t bytes = 0;
+    ~FragBuffer() {
+        if (dev) (void)hipFree(dev);  // waits for the device: in-flight kernels of a dead transient plan finish first
+    }
+};
 struct FragEntry {
     int tiles = 0;
-    void *dev = nullptr;  // meta | bias | frags
+    std::shared_ptr<FragBuffer> buf;  // meta | bias | frags
     uint64_t meta = 0, bias = 0, frags = 0;
     std::shared_ptr<std::vector<int32_t>> meta_host;  // [tiles][4], for sizing the LDS windows
 };
+constexpr size_t kFragCacheBytes = (size_t)256 << 20;
 }  // namespace
 
 struct mic_ctx {
@@ -130,6 +142,9 @@ struct mic_ctx {
     size_t arena_cap = 0;
     std::map<CoefKey, CoefEntry> coefs;
     std::map<CoefKey, FragEntry> frags;  // key.transposed unused (0)
+    std::deque<CoefKey> frag_order;      // insertion order, for eviction
+    size_t frag_bytes = 0;
+    size_t frag_cache_cap = kFragCacheBytes;  // MIC_FRAG_CACHE_MB at mic_create (tests shrink it)
     uint32_t *median_scratch = nullptr;  // device: histogram words + 1 result word
     uint32_t *gradient_table = nullptr;  // device: fill_gradient's per-position colours (allocated on first use)
     uint32_t *median_host = nullptr;     // pinned
@@ -182,6 +197,8 @@ extern "C" int mic_create(int device, mic_ctx **out) {
     mic_ctx *ctx = new (std::nothrow) mic_ctx();
     if (!ctx) return fail(MIC_ERR_NOMEM, "out of host memory");
     ctx->device = device;
+    if (const char *mb = getenv("MIC_FRAG_CACHE_MB"))
+        if (atoi(mb) > 0) ctx->frag_cache_cap = (size_t)atoi(mb) << 20;
     for (auto &s : ctx->slots) {
         e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
         if (e != hipSuccess) {
@@ -214,8 +231,7 @@ extern "C" int mic_destroy(mic_ctx *ctx) {
         if (kv.second.bounds) (void)hipFree(kv.second.bounds);
         if (kv.second.coeffs) (void)hipFree(kv.second.coeffs);
     }
-    for (auto &kv : ctx->frags)
-        if (kv.second.dev) (void)hipFree(kv.second.dev);
+    ctx->frags.clear();  // buffers free themselves (plans still alive keep theirs)
     for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->median_scratch) (void)hipFree(ctx->median_scratch);
@@ -314,8 +330,19 @@ static int get_frags(mic_ctx *ctx, int in, int out, int filter, FragEntry *res) 
     e.tiles = f.tiles;
     const size_t meta_b = align_up(f.meta.size() * sizeof(int32_t), 64);
     const size_t bias_b = align_up(f.bias.size() * sizeof(int32_t), 64);
-    HIP_TRY(hipMalloc(&e.dev, meta_b + bias_b + f.frags.size()));
-    e.meta = reinterpret_cast<uint64_t>(e.dev);
+    e.buf = std::make_shared<FragBuffer>();
+    e.buf->bytes = meta_b + bias_b + f.frags.size();
+    // bounded cache, oldest first (entries a live plan still points into stay allocated until it dies)
+    while (!ctx->frag_order.empty() && ctx->frag_bytes + e.buf->bytes > ctx->frag_cache_cap) {
+        auto old = ctx->frags.find(ctx->frag_order.front());
+        ctx->frag_order.pop_front();
+        if (old != ctx->frags.end()) {
+            ctx->frag_bytes -= old->second.buf->bytes;
+            ctx->frags.erase(old);
+        }
+    }
+    HIP_TRY(hipMalloc(&e.buf->dev, e.buf->bytes));
+    e.meta = reinterpret_cast<uint64_t>(e.buf->dev);
     e.bias = e.meta + meta_b;
     e.frags = e.bias + bias_b;
     // Pageable sources: the runtime stages them before returning.
@@ -324,6 +351,8 @@ static int get_frags(mic_ctx *ctx, int in, int out, int filter, FragEntry *res) 
     HIP_TRY(hipMemcpy(reinterpret_cast<void *>(e.frags), f.frags.data(), f.frags.size(), hipMemcpyHostToDevice));
     e.meta_host = std::make_shared<std::vector<int32_t>>(f.meta);
     ctx->frags[key] = e;
+    ctx->frag_order.push_back(key);
+    ctx->frag_bytes += e.buf->bytes;
     *res = e;
     return MIC_OK;
 }
@@ -523,6 +552,7 @@ struct ResizePlan {
 
 struct PassTables {
     std::vector<RsMfma> fused;
+    std::vector<std::shared_ptr<FragBuffer>> frag_refs;  // keeps the tables `fused` points into alive
     int fused_layers = 0;
     int fused_whole = 0;  // entries [0, fused_whole) keep their whole window in LDS, the rest are banded
     int fused_max_tiles = 0;
@@ -597,6 +627,8 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             FragEntry fh, fv;
             if (int rc = get_frags(ctx, p.sw, p.dw, filter, &fh)) return rc;
             if (int rc = get_frags(ctx, p.sh, p.dh, filter, &fv)) return rc;
+            pt->frag_refs.push_back(fh.buf);
+            pt->frag_refs.push_back(fv.buf);
             RsMfma f{};
             f.src = p.planar_src ? p.planar_src : p.src; f.dst = dst;
             f.planar_pitch = p.planar_src ? p.planar_pitch : 0;

@@ -196,3 +196,48 @@ def test_raw_abi_render_and_overlay(abi):
                                       cols.ctypes.data_as(U8P), 3, _stream()) < 0
     assert b"x1 must be greater than or equal to x0" in lib.mic_last_error()
     assert lib.mic_atlas_destroy(atlas) == 0
+
+
+def test_fragment_cache_eviction_keeps_plans_valid():
+    """The resample fragment tables are cached per (in, out, filter) axis with a byte cap; entries are
+    ref-counted, so evicting them must not disturb a persistent plan that still points into them."""
+    import os
+    import torch
+    from image_transformation_amd import _native
+    lib = _native.lib()
+    os.environ["MIC_FRAG_CACHE_MB"] = "1"
+    try:
+        ctx = P()
+        assert lib.mic_create(torch.cuda.current_device(), ctypes.byref(ctx)) == 0, lib.mic_last_error()
+    finally:
+        del os.environ["MIC_FRAG_CACHE_MB"]
+    rng = np.random.default_rng(31)
+    objs = {1: cases.synthetic.make_cutout(rng, 300, 200, "soft")}
+    atlas = _make_atlas(lib, ctx, objs)
+    W, H = 640, 480
+    pl = (_native.Placement * 1)(_native.Placement(0, 1, (ctypes.c_int32 * 4)(10, 20, 10 + 411, 20 + 333)))
+    job = _native.Job()
+    job.width, job.height, job.bg_dev, job.n_placements = W, H, None, 1
+    for k, v in enumerate((9, 8, 7, 255)):
+        job.bg_rgba[k] = v
+    job.placements = ctypes.cast(pl, ctypes.POINTER(_native.Placement))
+    out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    job.out_dev = out.data_ptr()
+    plan = P()
+    atl = (P * 1)(atlas)
+    assert lib.mic_plan_create(ctx, 1, atl, 1, ctypes.byref(job), 0, ctypes.byref(plan)) == 0, lib.mic_last_error()
+    bg = np.empty((H, W, 4), np.uint8); bg[:] = (9, 8, 7, 255)
+    want = oracle.composite(bg, objs, [{"object_id": 1, "box": [10, 20, 421, 353]}])
+    # churn through many other sizes: far more than 1 MB of tables, so the plan's entries leave the cache
+    src = torch.from_numpy(objs[1]).cuda()
+    for k in range(60):
+        dw, dh = 150 + 7 * k, 120 + 5 * k
+        dst = torch.empty((dh, dw, 4), dtype=torch.uint8, device="cuda")
+        assert lib.mic_resize(ctx, P(src.data_ptr()), 300, 200, P(dst.data_ptr()), dw, dh, 0, _stream()) == 0, lib.mic_last_error()
+        if k % 20 == 0:
+            assert np.array_equal(dst.cpu().numpy(), oracle.resize(objs[1], (dw, dh)))
+    for _ in range(2):
+        out.zero_()
+        assert lib.mic_plan_run(plan, None, _stream()) == 0, lib.mic_last_error()
+        assert np.array_equal(out.cpu().numpy(), want)
+    assert lib.mic_plan_destroy(plan) == 0 and lib.mic_atlas_destroy(atlas) == 0 and lib.mic_destroy(ctx) == 0
