@@ -240,4 +240,12 @@ def test_fragment_cache_eviction_keeps_plans_valid():
         out.zero_()
         assert lib.mic_plan_run(plan, None, _stream()) == 0, lib.mic_last_error()
         assert np.array_equal(out.cpu().numpy(), want)
+    # sampled event brackets: every 3rd of 9 runs is timed
+    assert lib.mic_profile_begin_sampled(ctx, 10, 3) == 0, lib.mic_last_error()
+    for _ in range(9):
+        assert lib.mic_plan_run(plan, None, _stream()) == 0
+    n, comp, res = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+    assert lib.mic_profile_end(ctx, _stream(), ctypes.byref(n), ctypes.byref(comp), ctypes.byref(res)) == 0
+    assert n.value == 3 and comp.value > 0 and res.value > 0
+    assert lib.mic_profile_begin_sampled(ctx, 10, 0) < 0
     assert lib.mic_plan_destroy(plan) == 0 and lib.mic_atlas_destroy(atlas) == 0 and lib.mic_destroy(ctx) == 0
