@@ -12,7 +12,7 @@ import threading
 from typing import Dict, Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmic.so")
+LIB_PATH = os.environ.get("MIC_LIB") or os.path.join(_HERE, "libmic.so")  # MIC_LIB: an alternative build (tuning runs)
 
 LANCZOS = 0
 BILINEAR = 1

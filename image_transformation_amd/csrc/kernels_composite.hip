@@ -125,7 +125,7 @@ struct Group {
 // with no divergent branch -- conditional loads made hipcc drain vmcnt between groups, one HBM
 // round trip after another.
 struct Tap {
-    int off;  // pixel offset from L.src (< 2^31: the host rejects layers of 2^31 pixels or more)
+    int off;  // pixel offset from L.src; the host keeps every layer at <= 2^30 - 8 px, so off * 4 + 16 fits 32 bits
     int sx;   // layer column under pixel 0; -kLaneNPx when this lane does not read the layer
 };
 

@@ -10,6 +10,7 @@
 //
 // One launch processes every resampled layer of a composite call (blockIdx.z = layer).
 #include <algorithm>
+#include <atomic>
 
 #include "mic_internal.h"
 
@@ -137,34 +138,47 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const RsJob *__restrict
     reinterpret_cast<gptr>(J.dst)[(size_t)yy * J.out_w + x] = o;
 }
 
-// Fused resize on the matrix cores: one workgroup produces a (16 tx16) x (16 ty16) tile of the FINAL
-// image.
+// Fused resize on the matrix cores, marching down column strips.
 //
 // A separable resample is a banded matrix product per axis -- out = in x K^T with K[x][k] the taps
 // of output sample x -- and it is exact integer arithmetic, so it maps onto v_mfma_i32_16x16x64_i8
 // without touching the result: the 8-bit samples are stored as signed bytes (s - 128, the constant
 // 128 * sum(taps) goes into the accumulator's initial value together with Pillow's 2^21 rounding
-// term) and each 22-bit tap is split into three signed-byte digits, c = d0 + 256 d1 + 65536 d2,
-// one MFMA per digit; acc0 + (acc1 << 8) + (acc2 << 16) is then exactly Pillow's int32 sum.  A
-// 16x16x64 MFMA covers 16 output samples and a 64-sample window -- wider than the band for any
-// scale down to ~1/3 -- so the zeros outside the band are free.  (The VALU version of this kernel
-// spent ~12 instructions per tap per pixel and was bound by integer issue: 0.20 ms for the 32
-// layers of the C3 placements workload.)
+// term) and each 22-bit tap is split into three signed-byte digits, c = d0 + 256 d1 + 65536 d2.
+// The three digit products are not summed afterwards; they are CHAINED through the accumulator:
+//     acc = mfma(data, d0, bias);  acc >>= 8;  acc = mfma(data, d1, acc);  acc >>= 8;
+//     acc = mfma(data, d2, acc);   out = sat8(acc >> 6)
+// which is Pillow's clip8((bias + sum) >> 22) exactly, because floor((x + floor(y / n)) / m) ==
+// floor((x + y / n) / m) for integers x, y and positive n, m (arithmetic shifts are floor divisions).
+// Two plain shifts per value replace the shift-adds of a digit recombination, and a channel needs one
+// 4-register accumulator instead of three -- registers are what decides this kernel: it is bound by
+// vector issue (profiles/r02_ubench_isa.txt: one wave alone issues a VALU instruction every ~8 cycles,
+// four waves per SIMD are needed to approach the 2-cycle rate, the matrix pipe takes ~10), so the
+// design goal is many resident waves, few instructions per value.
 //
-//   1. source window rows x columns -> LDS, premultiplied once per pixel, split into four channel
-//      planes [row][column] of signed bytes;
-//   2. horizontal pass: A = 16 window rows x 64 columns of one plane (ds_read_b128 per lane),
-//      B = the x-tile's tap digits (host-built fragments, resample_coeffs.cpp), D = 16 rows x 16
-//      outputs; clip8 -> the 8-bit intermediate Pillow keeps between its passes, written
-//      transposed into planes [x][row] so that the next pass again reads 16 consecutive bytes;
-//   3. vertical pass: A = the y-tile's tap digits, B = 64 intermediate rows x 16 columns,
-//      D = 16 output rows x 16 columns; clip8, interleave the planes, unpremultiply, store.
+// Work unit = one workgroup (4 waves) = a column strip of 64 output columns x `seg_tiles` tiles of 16
+// output rows of one layer; wave w owns the strip's x-tile w for both passes.  The unit marches down
+// the source in bands of 16 rows:
+//   1. the band's rows x the strip's column window come from the cutout's planar premultiplied copy
+//      (planarize_kernel) into LDS, 16 bytes per lane, prefetched one band ahead in registers;
+//   2. horizontal pass (wave w: 16 rows x 16 outputs of x-tile w, taps resident in registers) -> clip ->
+//      the 8-bit intermediate Pillow keeps between its passes, into the wave's PRIVATE ring of
+//      intermediate rows ([channel][x][ring row], 16-row slots), so the only workgroup barriers are the
+//      two around the shared source band;
+//   3. every tile of 16 output rows whose last tap row is now in the ring: vertical pass with the ring
+//      as the A operand (M = x), so a lane ends up with 4 horizontally adjacent pixels of one output row
+//      -> unpremultiply -> one 16-byte store.
+// Neither the source rows nor the horizontal pass are redone for vertical neighbours inside a unit (the
+// 64 x 64-tile version of round 1 re-read 2.1x the source and redid 25-40% of the horizontal pass).
+// Bands whose window holds no pixel of alpha > 0 (the corners around a cutout's shape) skip the
+// horizontal pass, and output tiles that only see such bands are stored as transparent black.
 // The k index of both operands is defined by the same (lane >> 4, byte) -> window position map, so
 // the result does not depend on the hardware's internal k order; C/D follow the documented
 // col = lane & 15, row = 4 (lane >> 4) + reg map.  Bit-exact with the two-pass kernels above.
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) v4i *gv4ptr;
+typedef u32x4 __attribute__((aligned(4))) u32x4_a4;  // 16-byte access, 4-byte alignment
 
 // v_perm_b32: result byte i = byte sel[i] of the 8-byte value {hi (bytes 4..7), lo (bytes 0..3)}.
 __device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
@@ -181,99 +195,68 @@ __device__ __forceinline__ uint32_t premultiply2_hi(uint32_t x, uint32_t a) {
     return t + byte_perm(t, t, 0x0c030c01u);                     // + {t.b1, 0, t.b3, 0}
 }
 
-// clip8 of four 32-bit sums -> four bytes of one word, byte i from v[i].  v_ashr_pk_u8_i32 shifts,
-// saturates to 0..255 and packs two values per instruction; it writes only D[15:0] (which is what
-// hipcc's own use of it gets wrong, see clip8), so the halves are masked/shifted explicitly.
-__device__ __forceinline__ uint32_t clip8x4(int v0, int v1, int v2, int v3) {
-    uint32_t lo, hi;
-    asm volatile("v_ashr_pk_u8_i32 %0, %1, %2, 22" : "=v"(lo) : "v"(v0), "v"(v1));
-    asm volatile("v_ashr_pk_u8_i32 %0, %1, %2, 22" : "=v"(hi) : "v"(v2), "v"(v3));
-    return (lo & 0xFFFFu) | (hi << 16);
+// sat8(v >> 6) of the four sums of an accumulator -> four bytes of one word, byte i from v[i].
+// v_ashr_pk_u8_i32 shifts, saturates to 0..255 and packs two values per instruction into D[15:0].  It is
+// issued through the compiler's builtin, not inline asm: the values come straight out of an MFMA, and the
+// wait states between an MFMA and a VALU read of its result are inserted by the compiler's hazard
+// recogniser, which does not look inside asm statements (an asm version read the accumulator early and
+// produced saturated garbage).  The builtin returns 16 bits, so the upper half's stale bits -- what
+// hipcc's own pattern-matched use of the instruction gets wrong, see clip8 -- are dropped explicitly.
+__device__ __forceinline__ uint32_t clip8x4(v4i v) {
+    const uint32_t lo = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(v[0], v[1], 6);
+    const uint32_t hi = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(v[2], v[3], 6);
+    return lo | (hi << 16);
 }
 
-// acc0 + (acc1 << 8) + (acc2 << 16) in Horner form, two v_lshl_add_u32 (hipcc re-associates the C
-// expression into two shifts and a three-operand add).
-__device__ __forceinline__ int combine(int a0, int a1, int a2) {
-    int t;
-    asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(t) : "v"(a2), "v"(a1));
-    asm("v_lshl_add_u32 %0, %1, 8, %2" : "=v"(t) : "v"(t), "v"(a0));
-    return t;
-}
+__device__ __forceinline__ v4i shr8(v4i v) { return v4i{v[0] >> 8, v[1] >> 8, v[2] >> 8, v[3] >> 8}; }
 
-// Phase 1 of the MFMA kernel: R rows x C columns of the source, starting at pixel index `origin`,
-// go to LDS premultiplied and split into four planes of signed bytes (s - 128).  Items = (row, group
-// of 4 columns), dealt round-robin to the 256 threads, indices advanced incrementally (no per-item
-// multiply or divide); four 16-byte loads are in flight per thread and the loads are unconditional
-// (index clamped to last4 = pixels - 4; the host keeps images smaller than 4 px off this kernel).
-// EDGE: C is not a multiple of 4 (only when the window ends at the image's right edge): the last
-// group of each row is re-read pixel by pixel.
-template <bool EDGE>
-__device__ __forceinline__ uint32_t load_window(gcptr src, int sw, int last4, int origin, int R, int C, uint8_t *srcP,
-                                                int pitch_c, int plane_s, int tid) {
-    uint32_t seen = 0;  // OR of the pixels this thread handled: bits 24-31 say whether any had alpha > 0
-    const int G = (C + 3) >> 2;
-    const int dq = 256 / G, dr = 256 - dq * G;
-    int rr = tid / G, g = tid - rr * G;
-    int gi = origin + rr * sw + 4 * g;   // pixel index in the source image
-    int lo = rr * pitch_c + 4 * g;       // byte offset in a plane
-    const int gi_step = dq * sw + 4 * dr, lo_step = dq * pitch_c + 4 * dr;
-    const int gi_wrap = sw - 4 * G, lo_wrap = pitch_c - 4 * G;
-    while (rr < R) {
-        int irr[4], ig[4], igi[4], ilo[4];
-        u32x4 v[4];
+// One 16 x 16 tile of all four channels through the digit chain -> per channel one word of clipped
+// bytes.  load(c, ch) returns the data operand (A) of channel c, 64-sample chunk ch; f = the first
+// chunk's tap digits (B); fbase = where the tile's fragments start (further chunks -- windows wider than
+// 64 samples: shrinks below ~1/3 -- are read from there).  SINGLE: one chunk, the four channels' chains
+// are written side by side so that each MFMA's latency is covered by the other channels' work.
+template <bool SINGLE, class Load>
+__device__ __forceinline__ void tile4(Load load, const v4i (&f)[3], gv4ptr fbase, int n_chunks, v4i bias,
+                                      uint32_t (&w)[4]) {
+    if (SINGLE) {
+        // two channels at a time: 2 x (operand + accumulator) live instead of 4 x (this kernel's register
+        // budget is what sets its occupancy), still two independent chains to hide each other's latency
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            irr[k] = rr; ig[k] = g; igi[k] = gi; ilo[k] = lo;
-            __builtin_memcpy(&v[k], (const void *)(src + min(gi, last4)), 16);
-            rr += dq; g += dr; gi += gi_step; lo += lo_step;
-            if (g >= G) { g -= G; ++rr; gi += gi_wrap; lo += lo_wrap; }
+        for (int c0 = 0; c0 < 4; c0 += 2) {
+            const v4i a0 = load(c0, 0), a1 = load(c0 + 1, 0);
+            v4i x = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, f[0], bias, 0, 0, 0);
+            v4i y = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, f[0], bias, 0, 0, 0);
+            x = shr8(x);
+            y = shr8(y);
+            x = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, f[1], x, 0, 0, 0);
+            y = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, f[1], y, 0, 0, 0);
+            x = shr8(x);
+            y = shr8(y);
+            x = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, f[2], x, 0, 0, 0);
+            y = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, f[2], y, 0, 0, 0);
+            w[c0] = clip8x4(x);
+            w[c0 + 1] = clip8x4(y);
+        }
+    } else {
+        v4i acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = bias;
+#pragma unroll 1
+        for (int d = 0; d < 3; ++d) {
+#pragma unroll 1
+            for (int ch = 0; ch < n_chunks; ++ch) {
+                const v4i e = fbase[(ch * 3 + d) * 64];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(load(c, ch), e, acc[c], 0, 0, 0);
+            }
+            if (d < 2) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = shr8(acc[c]);
+            }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (irr[k] >= R) break;
-            uint32_t px[4] = {v[k][0], v[k][1], v[k][2], v[k][3]};
-            if (EDGE && ig[k] == G - 1) {
-                const int left = C - 4 * ig[k];  // 1..3 valid pixels
-                px[0] = src[igi[k]];
-                px[1] = left > 1 ? src[igi[k] + 1] : 0u;
-                px[2] = left > 2 ? src[igi[k] + 2] : 0u;
-                px[3] = 0u;
-            }
-            seen |= px[0] | px[1] | px[2] | px[3];
-            uint32_t rb[4], ga[4];  // premultiplied {R, B} and {G, A} in bytes 1 and 3
-            // Cutouts are mostly binary-alpha (the reference's bundles have no partial alpha at all):
-            // when every pixel this wave holds has alpha 0 or 255, premultiplying is a select.
-            bool binary = true;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) binary = binary && ((px[j] >> 24) == 0u || (px[j] >> 24) == 255u);
-            if (__all(binary)) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t keep = (uint32_t)((int32_t)px[j] >> 31);  // alpha 255 -> all ones, 0 -> zero
-                    const uint32_t q = px[j] & keep;
-                    rb[j] = (q & 0x00FF00FFu) << 8;                           // bytes 1 and 3, like the general path
-                    ga[j] = q & 0xFF00FF00u;
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t a = px[j] >> 24;
-                    rb[j] = premultiply2_hi(px[j] & 0x00FF00FFu, a);
-                    // {G, 255}: div255(255 a + 128) == a keeps the alpha byte itself
-                    ga[j] = premultiply2_hi(byte_perm(px[j], px[j], 0x0c0d0c01u), a);
-                }
-            }
-            // 4 px x 2 lanes -> one word per plane: {c0, c1, c2, c3} of the four pixels
-            const uint32_t rb01 = byte_perm(rb[1], rb[0], 0x07030501u), rb23 = byte_perm(rb[3], rb[2], 0x07030501u);
-            const uint32_t ga01 = byte_perm(ga[1], ga[0], 0x07030501u), ga23 = byte_perm(ga[3], ga[2], 0x07030501u);
-            uint32_t *dst = reinterpret_cast<uint32_t *>(srcP + ilo[k]);
-            dst[0 * (plane_s >> 2)] = byte_perm(rb23, rb01, 0x05040100u) ^ 0x80808080u;  // R
-            dst[1 * (plane_s >> 2)] = byte_perm(ga23, ga01, 0x05040100u) ^ 0x80808080u;  // G
-            dst[2 * (plane_s >> 2)] = byte_perm(rb23, rb01, 0x07060302u) ^ 0x80808080u;  // B
-            dst[3 * (plane_s >> 2)] = byte_perm(ga23, ga01, 0x07060302u) ^ 0x80808080u;  // A
-        }
+        for (int c = 0; c < 4; ++c) w[c] = clip8x4(acc[c]);
     }
-    return seen;
 }
 
 // ---- resident planar copy of an atlas ------------------------------------------------------------
@@ -320,239 +303,217 @@ hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_i
     return hipGetLastError();
 }
 
-// Phase 1 from the planar copy: rows [r0, r0 + R) x 16-byte chunks [c_lo, c_lo + 16 G) of each plane go
-// to LDS as they are (an item = one chunk position, its four planes loaded back to back).  Returns
-// non-zero iff some pixel of the window has alpha > 0 (alpha bytes are stored as alpha ^ 0x80).
-__device__ __forceinline__ uint32_t load_window_planar(uint64_t planar, int pitch, size_t plane_bytes, int r0, int c_lo,
-                                                       int R, int G, uint8_t *srcP, int pitch_c, int plane_s, int tid) {
-    uint32_t seen = 0;
-    const int dq = 256 / G, dr = 256 - dq * G;
-    int rr = tid / G, g = tid - rr * G;
-    while (rr < R) {
-        const uint64_t gsrc = planar + (size_t)(r0 + rr) * pitch + c_lo + 16 * g;
-        v4i v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<gv4ptr>(gsrc + c * plane_bytes);
-        uint8_t *dst = srcP + rr * pitch_c + 16 * g;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) *reinterpret_cast<v4i *>(dst + c * plane_s) = v[c];
-        const int k = (int)0x80808080u;
-        seen |= (uint32_t)((v[3][0] ^ k) | (v[3][1] ^ k) | (v[3][2] ^ k) | (v[3][3] ^ k));
-        rr += dq;
-        g += dr;
-        if (g >= G) { g -= G; ++rr; }
+// Convert.c rgba2rgbA on the four pixels a lane holds after the vertical pass, straight from the
+// per-channel words (w[c] = channel c of pixels 0..3): c = min(255, floor(255 c' / a)) for 0 < a < 255,
+// the pixel as it is for a = 0 and a = 255.  Per channel one v_cvt_f32_ubyteN (which also picks the
+// byte), one fma and one v_cvt_pk_u8_f32 (round to nearest even, saturating, written into byte c of the
+// pixel word: profiles/r02_ubench_isa.txt), so the planar -> interleaved transposition costs nothing:
+//     RNE(c' * F[a] - 0.5 + 2^-9) == floor(255 c' / a)   whenever that is < 256, and >= 255.5 otherwise,
+// with F[a] = 255/a rounded to float and bumped up one ulp, F[0] = F[255] = 1 (then it returns c'):
+// the product exceeds the exact quotient by < 2^-13, the quotient's fractional part is a multiple of
+// 1/a <= 1 - 1/254, and 2^-9 sits strictly between the two.  Checked exhaustively over (a, c') in
+// tests/test_blend_identities.py with float32 arithmetic.
+__device__ __forceinline__ u32x4 unpremultiply4(const uint32_t (&w)[4], const float *recip) {
+    const float K = -0.5f + 0.001953125f;
+    u32x4 px;
+#define MIC_UNPREMUL_PX(X)                                                                              \
+    {                                                                                                   \
+        const uint32_t a = (w[3] >> (8 * X)) & 255u;                                                    \
+        const float F = recip[a];                                                                       \
+        uint32_t p = a << 24;                                                                           \
+        p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)((w[0] >> (8 * X)) & 255u), F, K), 0, p); \
+        p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)((w[1] >> (8 * X)) & 255u), F, K), 1, p); \
+        p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)((w[2] >> (8 * X)) & 255u), F, K), 2, p); \
+        px[X] = p;                                                                                      \
     }
-    return seen;
+    MIC_UNPREMUL_PX(0) MIC_UNPREMUL_PX(1) MIC_UNPREMUL_PX(2) MIC_UNPREMUL_PX(3)
+#undef MIC_UNPREMUL_PX
+    return px;
 }
 
-// One 16 x 16 output tile: acc[channel][digit] = bias + sum over the window's 64-sample chunks of
-// data x tap-digit fragments.  DATA_IS_A: the LDS bytes are the A operand (horizontal pass: rows of
-// a source plane), otherwise B (vertical pass: columns of an intermediate plane).  f = the first
-// chunk's fragments (kept in registers by the caller), fbase = where the tile's fragments start.
-template <bool DATA_IS_A>
-__device__ __forceinline__ void tile_mfma(v4i (&acc)[4][3], const uint8_t *data, int plane, const v4i (&f)[3],
-                                          gv4ptr fbase, int n_chunks, v4i bias) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const v4i d = *reinterpret_cast<const v4i *>(data + c * plane);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const v4i init = k == 0 ? bias : v4i{0, 0, 0, 0};
-            acc[c][k] = DATA_IS_A ? __builtin_amdgcn_mfma_i32_16x16x64_i8(d, f[k], init, 0, 0, 0)
-                                  : __builtin_amdgcn_mfma_i32_16x16x64_i8(f[k], d, init, 0, 0, 0);
-        }
-    }
-    for (int ch = 1; ch < n_chunks; ++ch) {  // windows wider than 64 samples (shrinks below ~1/3)
-        const v4i e[3] = {fbase[(ch * 3 + 0) * 64], fbase[(ch * 3 + 1) * 64], fbase[(ch * 3 + 2) * 64]};
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const v4i d = *reinterpret_cast<const v4i *>(data + 64 * ch + c * plane);
-#pragma unroll
-            for (int k = 0; k < 3; ++k)
-                acc[c][k] = DATA_IS_A ? __builtin_amdgcn_mfma_i32_16x16x64_i8(d, e[k], acc[c][k], 0, 0, 0)
-                                      : __builtin_amdgcn_mfma_i32_16x16x64_i8(e[k], d, acc[c][k], 0, 0, 0);
-        }
-    }
-}
-
-// Accumulators -> per channel one word holding the clipped bytes of the lane's 4 rows.
-__device__ __forceinline__ void tile_words(const v4i (&acc)[4][3], uint32_t (&w)[4]) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-        w[c] = clip8x4(combine(acc[c][0][0], acc[c][1][0], acc[c][2][0]), combine(acc[c][0][1], acc[c][1][1], acc[c][2][1]),
-                       combine(acc[c][0][2], acc[c][1][2], acc[c][2][2]), combine(acc[c][0][3], acc[c][1][3], acc[c][2][3]));
-}
-
-// 4 channels x 4 rows -> 4 RGBA pixels (byte transpose), unpremultiply, store column ox of rows oy..oy+3.
-__device__ __forceinline__ void store_pixels(const uint32_t (&w)[4], gptr dst, int dw, int dh, int ox, int oy,
-                                             const float *recip) {
+// The same four pixels when no lane of the wave holds a partial alpha: a 4 x 4 byte transpose.
+__device__ __forceinline__ u32x4 interleave4(const uint32_t (&w)[4]) {
     const uint32_t rg01 = byte_perm(w[1], w[0], 0x05010400u), rg23 = byte_perm(w[1], w[0], 0x07030602u);
     const uint32_t ba01 = byte_perm(w[3], w[2], 0x05010400u), ba23 = byte_perm(w[3], w[2], 0x07030602u);
-    const uint32_t px[4] = {byte_perm(ba01, rg01, 0x05040100u), byte_perm(ba01, rg01, 0x07060302u),
-                            byte_perm(ba23, rg23, 0x05040100u), byte_perm(ba23, rg23, 0x07060302u)};
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (ox < dw && oy + r < dh) dst[(uint32_t)((oy + r) * dw + ox)] = unpremultiply_with(px[r], recip);  // < 2^31 px
+    return u32x4{byte_perm(ba01, rg01, 0x05040100u), byte_perm(ba01, rg01, 0x07060302u),
+                 byte_perm(ba23, rg23, 0x05040100u), byte_perm(ba23, rg23, 0x07060302u)};
 }
 
-template <bool BANDED>
-__global__ __launch_bounds__(256) void resample_mfma_kernel(const RsMfma *__restrict__ jobs) {
+__global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const RsMarch *__restrict__ jobs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
-    const RsMfma J = jobs[blockIdx.y];
-    // XCD-aware tile order (see RsMfma): blockIdx.x & 7 is the XCD this workgroup lands on
-    const int tile = (((int)blockIdx.x + J.xcd_rot) & 7) * (4 * J.n_entries) + 4 * J.entry + ((int)blockIdx.x >> 3);
-    if (tile >= J.tiles_x * J.tiles_y) return;
-    const int tyi = tile / J.tiles_x, txi = tile - tyi * J.tiles_x;
-    const int xt0 = txi * J.tx16, yt0 = tyi * J.ty16;
-    const int n_xt = min(J.tx16, ((J.dw + 15) >> 4) - xt0), n_yt = min(J.ty16, ((J.dh + 15) >> 4) - yt0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float recip[256];            // unpremultiply factors 255/a: an LDS read per pixel
+    __shared__ v4i vm_lds[kRsMaxSegTiles];  // the unit's vertical tile table
+    __shared__ uint32_t band_alpha;         // does the band in LDS hold a pixel of alpha > 0
+    const RsMarch J = jobs[blockIdx.y];
+    // XCD-aware unit order (see RsMarch): blockIdx.x & 7 is the XCD this workgroup lands on
+    const int unit = (((int)blockIdx.x + J.xcd_rot) & 7) * (4 * J.n_entries) + 4 * J.entry + ((int)blockIdx.x >> 3);
+    if (unit >= J.strips * J.segs) return;
+    const int seg = unit / J.strips, strip = unit - seg * J.strips;
+    const int xt0 = strip * 4, n_xt = min(4, J.tiles_x - xt0);
+    const int yt0 = seg * J.seg_tiles, n_yt = min(J.seg_tiles, J.tiles_y - yt0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lh = lane >> 4;
 
     gv4ptr hmeta = reinterpret_cast<gv4ptr>(J.hmeta), vmeta = reinterpret_cast<gv4ptr>(J.vmeta);
-    const int c_lo = hmeta[xt0][0], c_hi = min(J.sw, hmeta[xt0 + n_xt - 1][3]);
-    const int r_lo = vmeta[yt0][0], r_hi = min(J.sh, vmeta[yt0 + n_yt - 1][3]);
-    const int R = r_hi - r_lo;
-    // columns are loaded in groups of 4: round the window up to that, inside the image
-    const int C = min((c_hi - c_lo + 3) & ~3, J.sw - c_lo);
-    const int plane_s = J.rows16 * J.pitch_c;       // bytes per source plane
-    const int plane_m = 16 * J.tx16 * J.pitch_r;    // bytes per intermediate plane
-    uint8_t *srcP = lds8;                           // [4][rows16][pitch_c]
-    uint8_t *midT = lds8 + 4 * plane_s;             // [4][16 tx16][pitch_r]
-    __shared__ float recip[256];                    // unpremultiply factors 255/a: an LDS read per pixel
-    recip[tid] = unpremul_factor((uint32_t)tid);
+    recip[tid] = (tid == 0 || tid == 255) ? 1.0f : unpremul_factor((uint32_t)tid);
+    if (tid < n_yt) vm_lds[tid] = vmeta[yt0 + tid];
+    const int c_lo = hmeta[xt0][0];  // the strip's first source column (a multiple of 16)
+    // 16-byte column chunks of a band: what the strip's tiles can touch, inside the cutout's padded rows
+    const int n16 = min(J.pitch_c >> 4, (J.planar_pitch - c_lo) >> 4);
+    const int plane_s = 16 * J.pitch_c, plane_r = 64 * J.pitch_r;
+    uint8_t *srcP = lds8;                 // [4][16][pitch_c]   the source band
+    uint8_t *ring = lds8 + 4 * plane_s;   // [4][64][pitch_r]   intermediate rows, 16-row slots
+    const int rmask = J.ring16 - 1;
+    const int band0 = vmeta[yt0][0] >> 4;                  // window starts are multiples of 16
+    const int band_last = (vmeta[yt0 + n_yt - 1][3] - 1) >> 4;
 
-    // ---- 1 + 2, per band of J.rows16 window rows (all of them at once unless the window is too tall
-    // for LDS -- deep shrinks -- in which case the source planes hold one band at a time and only the
-    // 8-bit intermediate covers the whole window).
-    // (Two instantiations: the banded loop keeps the loader's and the pass's registers alive together
-    // -- 192 VGPRs, two waves per SIMD -- which the common whole-window case must not pay for.)
-    int band0 = 0;
-    do {
-        const int Rb = BANDED ? min(J.rows16, R - band0) : R;
-        if (BANDED && band0 > 0) __syncthreads();  // the previous band's horizontal pass is done reading srcP
+    // ---- this wave's x-tile: horizontal taps stay in registers for the whole unit
+    const bool active = wave < n_xt;  // wave-uniform
+    const v4i hm_v = hmeta[xt0 + (active ? wave : 0)];  // the same for every lane: kept in scalar registers
+    const int hm[3] = {__builtin_amdgcn_readfirstlane(hm_v[0]), __builtin_amdgcn_readfirstlane(hm_v[1]),
+                       __builtin_amdgcn_readfirstlane(hm_v[2])};
+    const int hb = reinterpret_cast<gciptr>(J.hbias)[(xt0 + (active ? wave : 0)) * 16 + l15];
+    const v4i hbias = {hb, hb, hb, hb};
+    gv4ptr hfbase = reinterpret_cast<gv4ptr>(J.hfrag) + (size_t)hm[2] * 3 * 64 + lane;
+    const v4i hf[3] = {hfbase[0], hfbase[64], hfbase[128]};
+    const uint8_t *a0 = srcP + l15 * J.pitch_c + (hm[0] - c_lo) + 16 * lh;
+    uint8_t *m0 = ring + (wave * 16 + l15) * J.pitch_r + 4 * lh;
+    const uint8_t *r0 = ring + (wave * 16 + l15) * J.pitch_r;
+    gptr dst = reinterpret_cast<gptr>(J.dst);
+    const int ox = (xt0 + wave) * 16 + 4 * lh;
 
-        // ---- 1. source rows -> premultiplied signed-byte planes
-        uint32_t seen;
-        if (J.planar_pitch > 0)  // the atlas' resident planar copy: a straight 16-byte copy per lane
-            seen = load_window_planar(J.src, J.planar_pitch, (size_t)J.planar_pitch * J.sh, r_lo + band0, c_lo, Rb,
-                                      (c_hi - c_lo + 15) >> 4, srcP, J.pitch_c, plane_s, tid) ? 0xFF000000u : 0u;
-        else if ((C & 3) == 0)
-            seen = load_window<false>(reinterpret_cast<gcptr>(J.src), J.sw, J.sw * J.sh - 4, (r_lo + band0) * J.sw + c_lo,
-                                      Rb, C, srcP, J.pitch_c, plane_s, tid);
-        else  // the window ends at the image's right edge in the middle of a group of 4 columns
-            seen = load_window<true>(reinterpret_cast<gcptr>(J.src), J.sw, J.sw * J.sh - 4, (r_lo + band0) * J.sw + c_lo,
-                                     Rb, C, srcP, J.pitch_c, plane_s, tid);
-        if (!BANDED) {
-            // A window without a single pixel of alpha > 0 (the corners around a cutout's shape)
-            // premultiplies to all zeros, and both passes of zeros give clip8(2^21 >> 22) = 0: the tile is
-            // transparent black.
-            if (!__syncthreads_or((seen >> 24) != 0u)) {
-                gptr dst = reinterpret_cast<gptr>(J.dst);
-                const int ox0 = xt0 * 16, oy0 = yt0 * 16;
-                const int tw = min(16 * n_xt, J.dw - ox0), th = min(16 * n_yt, J.dh - oy0);
-                for (int yy = wave; yy < th; yy += 4)
-                    for (int xx = lane; xx < tw; xx += 64) dst[(uint32_t)((oy0 + yy) * J.dw + ox0 + xx)] = 0u;
-                return;
-            }
-        } else {
-            __syncthreads();
-        }
-
-        // ---- 2. horizontal pass: window rows -> 8-bit intermediate, transposed.  A wave keeps one
-        // x-tile (its tap fragments stay in registers) and walks the row tiles two at a time: the second
-        // tile's MFMAs run in the matrix pipe while the VALU does the first tile's epilogue.
-        const int groups = 4 / n_xt;  // waves per x-tile (n_xt <= 4)
-        if (wave < n_xt * groups) {
-            const int xi = wave % n_xt, sub = wave / n_xt;
-            const int n_rt = (Rb + 15) >> 4;
-            const v4i m = hmeta[xt0 + xi];
-            const int b = reinterpret_cast<gciptr>(J.hbias)[(xt0 + xi) * 16 + l15];
-            const v4i bias = {b, b, b, b};
-            gv4ptr fbase = reinterpret_cast<gv4ptr>(J.hfrag) + (size_t)m[2] * 3 * 64 + lane;
-            const v4i f[3] = {fbase[0], fbase[64], fbase[128]};
-            const uint8_t *a0 = srcP + l15 * J.pitch_c + (m[0] - c_lo) + 16 * lh;      // + 16 rt pitch_c
-            uint8_t *m0 = midT + (xi * 16 + l15) * J.pitch_r + band0 + 4 * lh;         // + 16 rt
-            for (int rt = sub; rt < n_rt; rt += 2 * groups) {
-                const int rt2 = rt + groups;
-                const bool two = rt2 < n_rt;  // wave-uniform
-                v4i acc[4][3], acc2[4][3];
-                tile_mfma<true>(acc, a0 + rt * 16 * J.pitch_c, plane_s, f, fbase, m[1], bias);
-                if (two) tile_mfma<true>(acc2, a0 + rt2 * 16 * J.pitch_c, plane_s, f, fbase, m[1], bias);
-                // D[row = 4 lh + reg (window row)][col = l15 (x)]: 4 consecutive rows of one column
-                uint32_t w[4];
-                tile_words(acc, w);
+    // ---- band loader: wave = plane, lane = (row, chunk mod 4); chunks cl, cl + 4, ... < n16
+    const int lrow = lane >> 2, cl = lane & 3;
+    const uint64_t gplane = J.src + (uint64_t)wave * ((uint64_t)J.planar_pitch * J.sh) + c_lo + 16 * cl;
+    uint8_t *lds_dst = srcP + wave * plane_s + lrow * J.pitch_c + 16 * cl;
+    v4i pre[2];
+    auto band_row = [&](int b) { return gplane + (uint64_t)min(16 * b + lrow, J.sh - 1) * J.planar_pitch; };
+    auto prefetch = [&](int b) {
+        const uint64_t g = band_row(b);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m0 + rt * 16 + c * plane_m) = w[c] ^ 0x80808080u;
-                if (two) {
-                    tile_words(acc2, w);
+        for (int k = 0; k < 2; ++k)
+            if (cl + 4 * k < n16) pre[k] = *reinterpret_cast<gv4ptr>(g + 64 * k);
+    };
+    prefetch(band0);
+
+    int yt = 0;           // next tile of output rows (relative to yt0) to emit
+    uint32_t zmask = 0;   // bit s: ring slot s holds an all-zero band
+    for (int b = band0; b <= band_last; ++b) {
+        __syncthreads();  // every wave is done reading the previous band
+        {
+            uint32_t seen = 0;  // alpha plane (wave 3): OR of (alpha ^ 0x80) bytes, zero iff every alpha is 0
+            const int k80 = (int)0x80808080u;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        *reinterpret_cast<uint32_t *>(m0 + rt2 * 16 + c * plane_m) = w[c] ^ 0x80808080u;
+            for (int k = 0; k < 2; ++k)
+                if (cl + 4 * k < n16) {
+                    *reinterpret_cast<v4i *>(lds_dst + 64 * k) = pre[k];
+                    seen |= (uint32_t)((pre[k][0] ^ k80) | (pre[k][1] ^ k80) | (pre[k][2] ^ k80) | (pre[k][3] ^ k80));
+                }
+            if (n16 > 8) {  // strips of deep shrinks: the rest of the band, not prefetched
+                const uint64_t g = band_row(b);
+                for (int k = 2; cl + 4 * k < n16; ++k) {
+                    const v4i v = *reinterpret_cast<gv4ptr>(g + 64 * k);
+                    *reinterpret_cast<v4i *>(lds_dst + 64 * k) = v;
+                    seen |= (uint32_t)((v[0] ^ k80) | (v[1] ^ k80) | (v[2] ^ k80) | (v[3] ^ k80));
                 }
             }
+            if (wave == 3) {
+                const bool any = __any(seen != 0u);
+                if (lane == 0) band_alpha = any ? 1u : 0u;
+            }
         }
-        band0 += J.rows16;
-    } while (BANDED && band0 < R);
-    __syncthreads();
-
-    // ---- 3. vertical pass + unpremultiply + store: a wave keeps one y-tile, walks the x-tiles
-    {
-        const int groups = 4 / n_yt;
-        if (wave < n_yt * groups) {
-            const int yi = wave % n_yt, sub = wave / n_yt;
-            const v4i m = vmeta[yt0 + yi];
-            const v4i bias = *reinterpret_cast<gv4ptr>(reinterpret_cast<gciptr>(J.vbias) + (yt0 + yi) * 16 + 4 * lh);
-            gv4ptr fbase = reinterpret_cast<gv4ptr>(J.vfrag) + (size_t)m[2] * 3 * 64 + lane;
-            const v4i f[3] = {fbase[0], fbase[64], fbase[128]};
-            const uint8_t *b0 = midT + l15 * J.pitch_r + (m[0] - r_lo) + 16 * lh;      // + 16 xi pitch_r
-            gptr dst = reinterpret_cast<gptr>(J.dst);
-            const int oy0 = (yt0 + yi) * 16 + 4 * lh;
-            for (int xi = sub; xi < n_xt; xi += 2 * groups) {
-                const int xi2 = xi + groups;
-                const bool two = xi2 < n_xt;
-                v4i acc[4][3], acc2[4][3];
-                tile_mfma<false>(acc, b0 + xi * 16 * J.pitch_r, plane_m, f, fbase, m[1], bias);
-                if (two) tile_mfma<false>(acc2, b0 + xi2 * 16 * J.pitch_r, plane_m, f, fbase, m[1], bias);
-                // D[row = 4 lh + reg (output row)][col = l15 (x)]: per channel the bytes of 4 rows
+        __syncthreads();  // the band (and its alpha flag) is in LDS
+        if (b < band_last) prefetch(b + 1);
+        const bool zero_band = __builtin_amdgcn_readfirstlane((int)band_alpha) == 0;
+        const int slot = b & rmask;
+        if (active) {
+            if (zero_band) {
+                // premultiplied zeros in, clip8(2^21 >> 22) = 0 out: the intermediate rows are zero
+                zmask |= 1u << slot;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m0 + 16 * slot + c * plane_r) = 0x80808080u;
+            } else {
+                zmask &= ~(1u << slot);
+                // D[row = 4 lh + reg (band row)][col = l15 (x)]: 4 consecutive rows of one column
                 uint32_t w[4];
-                tile_words(acc, w);
-                store_pixels(w, dst, J.dw, J.dh, (xt0 + xi) * 16 + l15, oy0, recip);
-                if (two) {
-                    tile_words(acc2, w);
-                    store_pixels(w, dst, J.dw, J.dh, (xt0 + xi2) * 16 + l15, oy0, recip);
+                auto load = [&](int c, int ch) { return *reinterpret_cast<const v4i *>(a0 + c * plane_s + 64 * ch); };
+                if (hm[1] == 1) tile4<true>(load, hf, hfbase, 1, hbias, w);
+                else tile4<false>(load, hf, hfbase, hm[1], hbias, w);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m0 + 16 * slot + c * plane_r) = w[c] ^ 0x80808080u;
+            }
+        }
+        // ---- tiles of output rows whose last tap row is now in the ring
+        while (yt < n_yt) {
+            const v4i vm = vm_lds[yt];
+            const int v_ws = __builtin_amdgcn_readfirstlane(vm[0]), v_nch = __builtin_amdgcn_readfirstlane(vm[1]);
+            const int v_frag = __builtin_amdgcn_readfirstlane(vm[2]), v_hi = __builtin_amdgcn_readfirstlane(vm[3]);
+            if (v_hi > 16 * (b + 1)) break;
+            if (active) {
+                const int oy = (yt0 + yt) * 16 + l15;
+                const bool inside = oy < J.dh && ox < J.dw;
+                const uint32_t o_idx = (uint32_t)(oy * J.dw + ox);  // < 2^30 px
+                bool all_zero = true;
+                for (int s = v_ws >> 4; s <= (v_hi - 1) >> 4; ++s) all_zero = all_zero && ((zmask >> (s & rmask)) & 1u);
+                u32x4 px = {0u, 0u, 0u, 0u};
+                if (!all_zero) {
+                    const int vb = reinterpret_cast<gciptr>(J.vbias)[(yt0 + yt) * 16 + l15];
+                    const v4i vbias = {vb, vb, vb, vb};
+                    gv4ptr vfbase = reinterpret_cast<gv4ptr>(J.vfrag) + (size_t)v_frag * 3 * 64 + lane;
+                    const v4i vf[3] = {vfbase[0], vfbase[64], vfbase[128]};
+                    const int base16 = (v_ws >> 4) + lh;
+                    uint32_t w[4];
+                    // A[m = l15 (x)][k = 16 lh + j (window row)]; D[row = 4 lh + reg (x)][col = l15 (output row)]
+                    auto load = [&](int c, int ch) {
+                        return *reinterpret_cast<const v4i *>(r0 + c * plane_r + (((base16 + 4 * ch) & rmask) << 4));
+                    };
+                    if (v_nch == 1) tile4<true>(load, vf, vfbase, 1, vbias, w);
+                    else tile4<false>(load, vf, vfbase, v_nch, vbias, w);
+                    // alpha bytes all 0 or 255 <=> low 7 bits of every byte equal its top bit
+                    const uint32_t top = (w[3] >> 7) & 0x01010101u;
+                    const bool soft = (w[3] & 0x7F7F7F7Fu) != (top << 7) - top;
+                    px = __any(soft) ? unpremultiply4(w, recip) : interleave4(w);
+                }
+                if (inside) {
+                    if (ox + 4 <= J.dw) {
+                        *reinterpret_cast<MIC_GLOBAL u32x4_a4 *>(dst + o_idx) = px;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j)
+                            if (ox + j < J.dw) dst[o_idx + j] = px[j];
+                    }
                 }
             }
+            ++yt;
         }
     }
 }
 
-// jobs_dev[0, n_whole) keep their whole source window in LDS, jobs_dev[n_whole, n_jobs) are banded.
-hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes,
-                                hipStream_t stream) {
+// jobs_dev[0, n_small) need at most kRsSmallLds bytes of LDS (several workgroups per CU), the rest more.
+hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, int n_small, size_t lds_small, size_t lds_large,
+                                 hipStream_t stream) {
     if (n_jobs <= 0) return hipSuccess;
-    // opt the kernels in for more than 64 KB of dynamic LDS, once per device of this process
-    static bool attr_set[64] = {};
+    // opt the kernel in for more than 64 KB of dynamic LDS, once per device of this process
+    // (atomic flags: two threads racing here both set the same attribute, which is harmless)
+    static std::atomic<bool> attr_set[64];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_mfma_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsMfmaMaxLds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_mfma_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsMfmaMaxLds);
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_march_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsMarchMaxLds);
         if (e != hipSuccess) return e;
-        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
-    for (int first = 0; first < n_whole; first += 65535) {  // grid.y limit
-        const int n = std::min(65535, n_whole - first);
-        hipLaunchKernelGGL(resample_mfma_kernel<false>, dim3((unsigned)kRsTilesPerEntry, (unsigned)n), dim3(256),
-                           lds_bytes, stream, jobs_dev + first);
+    for (int first = 0; first < n_small; first += 65535) {  // grid.y limit
+        const int n = std::min(65535, n_small - first);
+        hipLaunchKernelGGL(resample_march_kernel, dim3((unsigned)kRsUnitsPerEntry, (unsigned)n), dim3(256), lds_small,
+                           stream, jobs_dev + first);
     }
-    for (int first = n_whole; first < n_jobs; first += 65535) {
+    for (int first = n_small; first < n_jobs; first += 65535) {
         const int n = std::min(65535, n_jobs - first);
-        hipLaunchKernelGGL(resample_mfma_kernel<true>, dim3((unsigned)kRsTilesPerEntry, (unsigned)n), dim3(256),
-                           lds_bytes, stream, jobs_dev + first);
+        hipLaunchKernelGGL(resample_march_kernel, dim3((unsigned)kRsUnitsPerEntry, (unsigned)n), dim3(256), lds_large,
+                           stream, jobs_dev + first);
     }
     return hipGetLastError();
 }

@@ -12,6 +12,7 @@
 #include <deque>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <new>
 #include <tuple>
 #include <unordered_map>
@@ -58,6 +59,10 @@ constexpr size_t kPixelAlign = 256;
 // guard bands of at least kGuard readable bytes.
 constexpr size_t kGuard = 16;
 constexpr int64_t kMaxDim = 65535;
+// The composite kernel addresses a layer with an unsigned 32-bit BYTE offset (pixel offset * 4 + the
+// 16-byte guard bias, kernels_composite.hip: load_tap), so an image it reads holds at most this many
+// pixels -- atlas cutouts (also in blobs received from elsewhere) and resampled layers alike.
+constexpr int64_t kMaxLayerPx = ((int64_t)1 << 30) - 8;
 
 struct BlobHeader {
     uint32_t magic, version, n, reserved;
@@ -79,7 +84,7 @@ int blob_layout(int n, const int32_t *ids, const int32_t *w, const int32_t *h,
     const size_t pixels_offset = off;
     if (entries) entries->clear();
     for (int i = 0; i < n; ++i) {
-        if (w[i] <= 0 || h[i] <= 0 || w[i] > kMaxDim || h[i] > kMaxDim || (int64_t)w[i] * h[i] >= ((int64_t)1 << 31))
+        if (w[i] <= 0 || h[i] <= 0 || w[i] > kMaxDim || h[i] > kMaxDim || (int64_t)w[i] * h[i] > kMaxLayerPx)
             return fail(MIC_ERR_INVALID, "atlas: object %d has invalid size %dx%d", i, w[i], h[i]);
         if (entries) entries->push_back(BlobEntry{ids ? ids[i] : i, w[i], h[i], 0, off, 0});
         off = align_up(off + (size_t)w[i] * h[i] * 4 + kGuard, kPixelAlign);
@@ -121,8 +126,14 @@ struct CoefEntry {
 struct FragBuffer {
     void *dev = nullptr;
     size_t bytes = 0;
+    int device = 0;  // the last reference may die on a thread whose current device is another one
     ~FragBuffer() {
-        if (dev) (void)hipFree(dev);  // waits for the device: in-flight kernels of a dead transient plan finish first
+        if (!dev) return;
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        (void)hipFree(dev);  // waits for the device: in-flight kernels of a dead transient plan finish first
+        if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
     }
 };
 struct FragEntry {
@@ -135,6 +146,11 @@ constexpr size_t kFragCacheBytes = (size_t)256 << 20;
 }  // namespace
 
 struct mic_ctx {
+    // Every entry point that takes the context (or a plan / atlas of it) holds this lock for the whole
+    // call: the staging ring, the arena, the table caches and last_stream are shared state.  Recursive
+    // because mic_render calls mic_composite_batch.  (The Pillow calls this library replaces are
+    // thread-safe, and the reference's Streamlit app runs every session on its own thread.)
+    mutable std::recursive_mutex mu;
     int device = 0;
     Slot slots[kSlots];
     int next_slot = 0;
@@ -159,6 +175,7 @@ struct mic_ctx {
 
 struct mic_atlas {
     mic_ctx *ctx = nullptr;
+    int device = 0;  // copy of ctx->device: mic_atlas_destroy must work after mic_destroy(ctx)
     void *blob = nullptr;
     size_t bytes = 0;
     bool owns = false;
@@ -166,17 +183,21 @@ struct mic_atlas {
     std::vector<BlobEntry> entries;
     std::unordered_map<int32_t, int> index;
     // resident planar premultiplied copy of every cutout (built by the first resample that needs it)
-    mutable int resample_calls = 0;             // composite calls that resampled cutouts of this atlas
-    mutable void *planar = nullptr;             // (a cache: filled through const atlases)
+    // Resident planar premultiplied copies of the cutouts that have been resampled (a cache: filled
+    // through const atlases, cutout by cutout, by the first call that resamples it).  Ref-counted like
+    // the fragment tables: a persistent plan whose pass tables point into the buffer keeps it alive past
+    // mic_atlas_destroy.
+    mutable std::shared_ptr<FragBuffer> planar;
     mutable std::vector<uint64_t> planar_off;   // per entry, bytes from `planar`
     mutable std::vector<int32_t> planar_pitch;
+    mutable std::vector<uint8_t> planar_built;  // per entry
 };
 
-static int ctx_enter(mic_ctx *ctx) {
-    if (!ctx) return fail(MIC_ERR_INVALID, "null context");
-    HIP_TRY(hipSetDevice(ctx->device));
-    return MIC_OK;
-}
+// Lock the context for the rest of the calling function and make its device current.
+#define CTX_ENTER(ctx)                                                   \
+    if (!(ctx)) return fail(MIC_ERR_INVALID, "null context");            \
+    std::lock_guard<std::recursive_mutex> ctx_lock_((ctx)->mu);          \
+    HIP_TRY(hipSetDevice((ctx)->device))
 
 extern "C" int mic_create(int device, mic_ctx **out) {
     if (!out) return fail(MIC_ERR_INVALID, "mic_create: null out");
@@ -242,7 +263,8 @@ extern "C" int mic_destroy(mic_ctx *ctx) {
 }
 
 extern "C" int mic_sync(mic_ctx *ctx, void *stream) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    if (!ctx) return fail(MIC_ERR_INVALID, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));  // no context state is touched: other threads are not kept waiting
     HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return MIC_OK;
 }
@@ -331,6 +353,7 @@ static int get_frags(mic_ctx *ctx, int in, int out, int filter, FragEntry *res) 
     const size_t meta_b = align_up(f.meta.size() * sizeof(int32_t), 64);
     const size_t bias_b = align_up(f.bias.size() * sizeof(int32_t), 64);
     e.buf = std::make_shared<FragBuffer>();
+    e.buf->device = ctx->device;
     e.buf->bytes = meta_b + bias_b + f.frags.size();
     // bounded cache, oldest first (entries a live plan still points into stay allocated until it dies)
     while (!ctx->frag_order.empty() && ctx->frag_bytes + e.buf->bytes > ctx->frag_cache_cap) {
@@ -385,12 +408,13 @@ static int atlas_finish(mic_atlas *a) {
         a->index.emplace(a->entries[i].id, (int)i);
     }
     a->uid = a->ctx->next_atlas_uid++;
+    a->device = a->ctx->device;
     return MIC_OK;
 }
 
 extern "C" int mic_atlas_create(mic_ctx *ctx, int n, const int32_t *ids, const int32_t *widths,
                                 const int32_t *heights, const uint8_t *const *rgba_host, mic_atlas **out) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    CTX_ENTER(ctx);
     if (!out || (n > 0 && (!ids || !widths || !heights || !rgba_host)))
         return fail(MIC_ERR_INVALID, "mic_atlas_create: null argument");
     *out = nullptr;
@@ -424,7 +448,7 @@ extern "C" int mic_atlas_create(mic_ctx *ctx, int n, const int32_t *ids, const i
 
 extern "C" int mic_atlas_from_device_blob(mic_ctx *ctx, const void *blob_dev, size_t bytes,
                                           const void *header_host, mic_atlas **out) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    CTX_ENTER(ctx);
     if (!blob_dev || !out) return fail(MIC_ERR_INVALID, "mic_atlas_from_device_blob: null argument");
     *out = nullptr;
     if (bytes < sizeof(BlobHeader)) return fail(MIC_ERR_FORMAT, "atlas blob shorter than its header");
@@ -443,7 +467,8 @@ extern "C" int mic_atlas_from_device_blob(mic_ctx *ctx, const void *blob_dev, si
                                sizeof(BlobEntry) * h.n, hipMemcpyDeviceToHost));
     }
     for (const BlobEntry &e : entries) {
-        if (e.w <= 0 || e.h <= 0 || e.w > kMaxDim || e.h > kMaxDim || e.offset % 4 != 0 || e.offset < kGuard ||
+        if (e.w <= 0 || e.h <= 0 || e.w > kMaxDim || e.h > kMaxDim || (int64_t)e.w * e.h > kMaxLayerPx ||
+            e.offset % 4 != 0 || e.offset < kGuard ||
             e.offset + (uint64_t)e.w * e.h * 4 + kGuard > h.total_bytes)
             return fail(MIC_ERR_FORMAT, "atlas blob: entry for id %d is out of bounds", e.id);
     }
@@ -482,168 +507,185 @@ extern "C" int mic_atlas_lookup(const mic_atlas *atlas, int32_t id, int32_t *wid
 
 extern "C" int mic_atlas_destroy(mic_atlas *atlas) {
     if (!atlas) return MIC_OK;
-    if ((atlas->owns && atlas->blob) || atlas->planar) {
-        (void)hipSetDevice(atlas->ctx->device);
+    if (atlas->owns && atlas->blob) {
+        (void)hipSetDevice(atlas->device);
         (void)hipDeviceSynchronize();
-        if (atlas->owns && atlas->blob) (void)hipFree(atlas->blob);
-        if (atlas->planar) (void)hipFree(atlas->planar);
+        (void)hipFree(atlas->blob);
     }
-    delete atlas;
+    delete atlas;  // the planar copy goes with its last reference (plans may still hold one)
     return MIC_OK;
 }
 
-// The atlas' planar premultiplied copy (kernels_resample.hip: planarize_kernel), built once, on the
-// default stream, and waited for: every later launch on any stream sees it.
-static int atlas_ensure_planar(const mic_atlas *A) {
-    if (A->planar || A->entries.empty()) return MIC_OK;
+// Planar premultiplied copies (kernels_resample.hip: planarize_kernel) of the cutouts in `need`, the form
+// the marching resample kernel reads.  Premultiplying and planarising is a pure function of the cutout
+// and the atlas outlives every composite / refine iteration / batch, so each cutout is converted once, by
+// the first call that resamples it (+4 B/px of HBM for those cutouts; the buffer is sized for the whole
+// atlas the first time).  Runs on the stream of the calling entry point (job table through the staging
+// ring): the context is driven from one stream at a time and adopt_stream() orders a later stream behind
+// this one, so every later launch sees the copies without a device-wide synchronisation here.
+static int atlas_ensure_planar(const mic_atlas *A, const std::vector<int> &need, hipStream_t stream) {
+    mic_ctx *ctx = A->ctx;
     const size_t n = A->entries.size();
-    std::vector<PlanarJob> jobs(n);
-    A->planar_off.assign(n, 0);
-    A->planar_pitch.assign(n, 0);
-    size_t total = 0;
-    int64_t max_items = 0;
-    for (size_t i = 0; i < n; ++i) {
-        const BlobEntry &e = A->entries[i];
-        const int pitch = (e.w + 15) / 16 * 16;
-        A->planar_off[i] = total;
-        A->planar_pitch[i] = pitch;
-        total = align_up(total + (size_t)4 * e.h * pitch, 256);
-        max_items = std::max<int64_t>(max_items, (int64_t)(pitch / 4) * e.h);
-    }
-    void *buf = nullptr, *jobs_dev = nullptr;
-    HIP_TRY(hipMalloc(&buf, total));
-    hipError_t e = hipMalloc(&jobs_dev, sizeof(PlanarJob) * n);
-    if (e == hipSuccess) {
+    if (!A->planar) {
+        std::vector<uint64_t> off(n);
+        std::vector<int32_t> pitches(n);
+        size_t total = 0;
         for (size_t i = 0; i < n; ++i) {
-            jobs[i].src = reinterpret_cast<uint64_t>(A->blob) + A->entries[i].offset;
-            jobs[i].dst = reinterpret_cast<uint64_t>(buf) + A->planar_off[i];
-            jobs[i].w = A->entries[i].w; jobs[i].h = A->entries[i].h; jobs[i].pitch = A->planar_pitch[i];
+            const BlobEntry &e = A->entries[i];
+            const int pitch = (e.w + 15) / 16 * 16;
+            off[i] = total;
+            pitches[i] = pitch;
+            total = align_up(total + (size_t)4 * e.h * pitch, 256);
         }
-        e = hipMemcpy(jobs_dev, jobs.data(), sizeof(PlanarJob) * n, hipMemcpyHostToDevice);
+        auto buf = std::make_shared<FragBuffer>();
+        buf->device = ctx->device;
+        buf->bytes = total;
+        HIP_TRY(hipMalloc(&buf->dev, total));
+        A->planar_off = std::move(off);
+        A->planar_pitch = std::move(pitches);
+        A->planar_built.assign(n, 0);
+        A->planar = std::move(buf);
     }
-    if (e == hipSuccess) e = launch_planarize(static_cast<const PlanarJob *>(jobs_dev), (int)n, max_items, nullptr);
-    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-    if (jobs_dev) (void)hipFree(jobs_dev);
-    if (e != hipSuccess) {
-        (void)hipFree(buf);
-        A->planar_off.clear();
-        A->planar_pitch.clear();
-        return fail(MIC_ERR_HIP, "building the atlas' planar copy: %s", hipGetErrorString(e));
+    std::vector<PlanarJob> jobs;
+    int64_t max_items = 0;
+    for (int i : need) {
+        if (A->planar_built[(size_t)i]) continue;
+        A->planar_built[(size_t)i] = 1;
+        const BlobEntry &e = A->entries[(size_t)i];
+        PlanarJob j{};
+        j.src = reinterpret_cast<uint64_t>(A->blob) + e.offset;
+        j.dst = reinterpret_cast<uint64_t>(A->planar->dev) + A->planar_off[(size_t)i];
+        j.w = e.w; j.h = e.h; j.pitch = A->planar_pitch[(size_t)i];
+        jobs.push_back(j);
+        max_items = std::max<int64_t>(max_items, (int64_t)(j.pitch / 4) * e.h);
     }
-    A->planar = buf;
+    if (jobs.empty()) return MIC_OK;
+    Slot *slot = nullptr;
+    if (int rc = acquire_slot(ctx, sizeof(PlanarJob) * jobs.size(), &slot)) return rc;
+    memcpy(slot->host, jobs.data(), sizeof(PlanarJob) * jobs.size());
+    HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, sizeof(PlanarJob) * jobs.size(), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(slot->ev, stream));
+    slot->pending = true;
+    HIP_TRY(launch_planarize(static_cast<const PlanarJob *>(slot->dev), (int)jobs.size(), max_items, stream));
     return MIC_OK;
 }
 
 // ------------------------------------------------------------------------------------ resample planning
 namespace {
 
-// One layer that needs Image.resize: up to two axis passes through the arena.
+// One layer that needs Image.resize.
 struct ResizePlan {
     uint64_t src;
     int sw, sh, dw, dh;
     size_t tmp_off = 0;   // scratch offset of the horizontal pass output (two-pass fallback, both axes)
     size_t dst_off = 0;   // scratch offset of the final image (unused when dst_ptr is set)
     uint64_t dst_ptr = 0; // caller-provided destination (mic_resize)
-    // MFMA kernel (source planes + 8-bit intermediate in LDS); tx16 == 0: two-pass fallback
-    int tx16 = 0, ty16 = 0, pitch_c = 0, pitch_r = 0, rows16 = 0;
-    uint64_t planar_src = 0;  // the cutout in its atlas' planar premultiplied copy (0: none, e.g. mic_resize)
+    // marching MFMA kernel (source band + ring of intermediate rows in LDS); march == false: two-pass fallback
+    bool march = false;
+    int pitch_c = 0, ring16 = 0, pitch_r = 0;
+    uint64_t planar_src = 0;  // the source's planar premultiplied copy (atlas copy, or arena scratch for mic_resize)
     int planar_pitch = 0;
 };
 
 struct PassTables {
-    std::vector<RsMfma> fused;
+    std::vector<RsMarch> fused;
     std::vector<std::shared_ptr<FragBuffer>> frag_refs;  // keeps the tables `fused` points into alive
     int fused_layers = 0;
-    int fused_whole = 0;  // entries [0, fused_whole) keep their whole window in LDS, the rest are banded
-    int fused_max_tiles = 0;
-    size_t fused_lds = 0;
+    int fused_small = 0;  // entries [0, fused_small) fit kRsMarchSmallLds, the rest need more LDS
+    size_t lds_small = 0, lds_large = 0;
     std::vector<RsJob> h, v;
     int max_h_out_w = 0, max_h_rows = 0, max_v_out_w = 0, max_v_out_h = 0;
 };
 
-// Over all workgroup tiles of `per` 16-sample tiles along one axis: the largest window extent the
-// kernel may touch (first tile's window start .. end of the last 64-sample chunk of any of its
-// tiles) and the largest span of samples it actually needs (.. one past the last tap).
-void window_extents(const std::vector<int32_t> &meta, int tiles, int per, int *touched, int *needed) {
-    *touched = 0;
-    *needed = 0;
+// Over all groups of `per` consecutive 16-sample tiles along one axis: the largest window extent a
+// group's tiles may touch (first tile's window start .. end of the last 64-sample chunk of any tile).
+int window_touched(const std::vector<int32_t> &meta, int tiles, int per) {
+    int touched = 0;
     for (int t0 = 0; t0 < tiles; t0 += per) {
         const int t1 = std::min(tiles, t0 + per);
         const int lo = meta[4 * t0];
         int end = lo;
         for (int t = t0; t < t1; ++t) end = std::max(end, meta[4 * t] + 64 * meta[4 * t + 1]);
-        *touched = std::max(*touched, end - lo);
-        *needed = std::max(*needed, meta[4 * (t1 - 1) + 3] - lo);
+        touched = std::max(touched, end - lo);
     }
+    return touched;
 }
 
 int round16(int v) { return (v + 15) / 16 * 16; }
 
-// Pick the workgroup tile of the MFMA kernel for one layer: the biggest of a short list whose
-// source planes + intermediate planes fit LDS, preferring sizes that let two workgroups share a CU.
-// Leaves tx16 == 0 when nothing fits (extreme shrinks: the two-pass kernels take those).
-int choose_fused(mic_ctx *ctx, ResizePlan *p, int filter) {
+// Size the marching kernel's LDS for one layer: the source band covers what the 4 x-tiles of a strip can
+// touch, the ring holds the 16-row slots between the first and the last tap row of any tile of 16 output
+// rows (a tile is emitted as soon as its last band is in).  Leaves march == false when that does not
+// fit (extreme shrinks: the two-pass kernels take those).
+int choose_march(mic_ctx *ctx, ResizePlan *p, int filter) {
     FragEntry fh, fv;
     if (int rc = get_frags(ctx, p->sw, p->dw, filter, &fh)) return rc;
     if (int rc = get_frags(ctx, p->sh, p->dh, filter, &fv)) return rc;
-    static const int kTiles[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
-    p->tx16 = 0;
-    if ((int64_t)p->sw * p->sh < 4) return MIC_OK;  // the kernel's 16-byte loads need 4 pixels to clamp into
-    if ((int64_t)p->sw * p->sh >= ((int64_t)1 << 30)) return MIC_OK;  // its 32-bit pixel index steps past the end
-    // Whole window resident first (preferred LDS size, then anything that fits); only windows too tall
-    // for that (deep shrinks) get source planes that hold one band of rows at a time.  Those have few
-    // output tiles, so the banded candidates go from the smallest tile up (more workgroups), with
-    // enough row tiles per band to keep the four waves busy.
-    for (const bool banded : {false, true}) {
-        for (const size_t cap : {kRsMfmaPreferredLds, kRsMfmaMaxLds}) {
-            for (int ti = 0; ti < 5; ++ti) {
-                const auto &t = kTiles[banded ? 4 - ti : ti];
-                int tc, nc, tr, nr;
-                window_extents(*fh.meta_host, fh.tiles, t[0], &tc, &nc);
-                window_extents(*fv.meta_host, fv.tiles, t[1], &tr, &nr);
-                // Pitches cover what a tile needs, not what its 64-sample chunks touch: a read past the
-                // end of a row lands in the next row (or in the 64 bytes of slack after the last one)
-                // and meets zero tap digits.
-                (void)tc; (void)tr;
-                const int pitch_c = round16(nc), pitch_r = round16(nr);
-                const int rows16 = banded ? std::min(pitch_r, std::max(16, 64 / t[0])) : pitch_r;
-                if (banded && rows16 == pitch_r) continue;  // same as the unbanded candidate
-                if (rs_mfma_lds_bytes(rows16, pitch_c, t[0], pitch_r) <= cap) {
-                    p->tx16 = t[0]; p->ty16 = t[1]; p->pitch_c = pitch_c; p->pitch_r = pitch_r; p->rows16 = rows16;
-                    return MIC_OK;
-                }
-            }
-        }
-    }
+    p->march = false;
+    int pitch_c = round16(window_touched(*fh.meta_host, fh.tiles, 4));
+    if ((pitch_c / 16) % 2 == 0) pitch_c += 16;  // an odd number of 16-byte units per row spreads the rows over the banks
+    int slots = 1;
+    const std::vector<int32_t> &vm = *fv.meta_host;
+    for (int t = 0; t < fv.tiles; ++t) slots = std::max(slots, (vm[4 * t + 3] - 1) / 16 - vm[4 * t] / 16 + 1);
+    int ring16 = 4;
+    while (ring16 < slots) ring16 *= 2;
+    if (ring16 > 32) return MIC_OK;  // the kernel tracks empty ring slots in a 32-bit mask
+    const int pitch_r = 16 * ring16 + 16;
+    if (rs_march_lds_bytes(pitch_c, pitch_r) > kRsMarchMaxLds) return MIC_OK;
+    p->march = true; p->pitch_c = pitch_c; p->ring16 = ring16; p->pitch_r = pitch_r;
     return MIC_OK;
+}
+
+// Pixels one work unit of the marching kernel should produce: enough units to fill every CU several
+// workgroups deep, few enough that the rows a unit re-does at its top (the vertical taps' reach) stay a
+// small share.  MIC_RS_UNIT_PX overrides (tuning).
+int64_t march_unit_px(int64_t total_px) {
+    static const int64_t forced = [] { const char *e = getenv("MIC_RS_UNIT_PX"); return e ? atoll(e) : 0ll; }();
+    if (forced > 0) return forced;
+    const int64_t target_units = 256 * 5 * 2;  // CUs x resident workgroups x two rounds
+    return std::max<int64_t>(64 * 48, std::min<int64_t>(total_px / target_units, 64 * 1024));
 }
 
 int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, void *scratch, PassTables *pt) {
     const uint64_t arena = reinterpret_cast<uint64_t>(scratch);
+    int64_t march_px = 0;
+    for (const ResizePlan &p : plans)
+        if (p.march) march_px += (int64_t)p.dw * p.dh;
+    const int64_t unit_px = march_unit_px(march_px);
     for (const ResizePlan &p : plans) {
         const bool need_h = p.dw != p.sw, need_v = p.dh != p.sh;
         const uint64_t dst = p.dst_ptr ? p.dst_ptr : arena + p.dst_off;
-        if (p.tx16 > 0) {
+        if (p.march) {
             FragEntry fh, fv;
             if (int rc = get_frags(ctx, p.sw, p.dw, filter, &fh)) return rc;
             if (int rc = get_frags(ctx, p.sh, p.dh, filter, &fv)) return rc;
             pt->frag_refs.push_back(fh.buf);
             pt->frag_refs.push_back(fv.buf);
-            RsMfma f{};
-            f.src = p.planar_src ? p.planar_src : p.src; f.dst = dst;
-            f.planar_pitch = p.planar_src ? p.planar_pitch : 0;
+            RsMarch f{};
+            f.src = p.planar_src; f.dst = dst;
+            f.planar_pitch = p.planar_pitch;
             f.hmeta = fh.meta; f.hbias = fh.bias; f.hfrag = fh.frags;
             f.vmeta = fv.meta; f.vbias = fv.bias; f.vfrag = fv.frags;
             f.sw = p.sw; f.sh = p.sh; f.dw = p.dw; f.dh = p.dh;
-            f.tx16 = p.tx16; f.ty16 = p.ty16;
-            f.tiles_x = (fh.tiles + p.tx16 - 1) / p.tx16; f.tiles_y = (fv.tiles + p.ty16 - 1) / p.ty16;
-            f.pitch_c = p.pitch_c; f.pitch_r = p.pitch_r; f.rows16 = p.rows16;
-            const int n_tiles = f.tiles_x * f.tiles_y;
-            f.n_entries = (n_tiles + kRsTilesPerEntry - 1) / kRsTilesPerEntry;
-            f.xcd_rot = pt->fused_layers++ & 7;  // the XCD that gets a layer's short last band rotates
+            f.tiles_x = fh.tiles; f.tiles_y = fv.tiles;
+            f.strips = (fh.tiles + 3) / 4;
+            // segments of equal height: about unit_px / 64 rows per unit, counted on whichever side has
+            // more of them (a unit's time goes with the source bands it marches through as much as with
+            // the output tiles it emits: a 2x shrink has twice the bands per output tile)
+            const double rows_per_tile = 16.0 * std::max(1.0, (double)p.sh / p.dh);
+            const int64_t want = std::max<int64_t>(1, (int64_t)((double)unit_px / 64.0 / rows_per_tile + 0.5));
+            const int seg_cap = (int)std::min<int64_t>(want, kRsMaxSegTiles);
+            f.segs = (fv.tiles + seg_cap - 1) / seg_cap;
+            f.seg_tiles = (fv.tiles + f.segs - 1) / f.segs;
+            f.segs = (fv.tiles + f.seg_tiles - 1) / f.seg_tiles;
+            f.pitch_c = p.pitch_c; f.ring16 = p.ring16; f.pitch_r = p.pitch_r;
+            const int n_units = f.strips * f.segs;
+            f.n_entries = (n_units + kRsUnitsPerEntry - 1) / kRsUnitsPerEntry;
+            f.xcd_rot = pt->fused_layers++ & 7;  // the XCD that gets a layer's short last run rotates
             for (f.entry = 0; f.entry < f.n_entries; ++f.entry) pt->fused.push_back(f);
-            pt->fused_max_tiles = kRsTilesPerEntry;
-            pt->fused_lds = std::max(pt->fused_lds, rs_mfma_lds_bytes(f.rows16, f.pitch_c, f.tx16, f.pitch_r));
+            const size_t lds = rs_march_lds_bytes(f.pitch_c, f.pitch_r);
+            if (lds <= kRsMarchSmallLds) pt->lds_small = std::max(pt->lds_small, lds);
+            else pt->lds_large = std::max(pt->lds_large, lds);
             continue;
         }
         uint64_t v_src = p.src;
@@ -681,9 +723,17 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             pt->max_v_out_h = std::max(pt->max_v_out_h, p.dh);
         }
     }
-    // whole-window entries first, banded ones after (two kernel instantiations, launch_resample_mfma)
-    auto whole = [](const RsMfma &f) { return f.rows16 >= f.pitch_r; };
-    pt->fused_whole = (int)(std::stable_partition(pt->fused.begin(), pt->fused.end(), whole) - pt->fused.begin());
+    // Entries with small LDS first (more workgroups per CU), the rest after, as two launches -- unless the
+    // rest is modest too: a second launch of a few entries is a serial tail (one unit's latency, ~20 us)
+    // that costs more than running everything at the larger size.
+    if (pt->lds_large > 0 && pt->lds_large <= kRsMarchMergeLds) {
+        pt->lds_small = std::max(pt->lds_small, pt->lds_large);
+        pt->lds_large = 0;
+        pt->fused_small = (int)pt->fused.size();
+        return MIC_OK;
+    }
+    auto small = [](const RsMarch &f) { return rs_march_lds_bytes(f.pitch_c, f.pitch_r) <= kRsMarchSmallLds; };
+    pt->fused_small = (int)(std::stable_partition(pt->fused.begin(), pt->fused.end(), small) - pt->fused.begin());
     return MIC_OK;
 }
 
@@ -697,6 +747,7 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
 // launches.  Pixel work is redone on every run -- nothing is cached but addresses.
 struct mic_plan {
     mic_ctx *ctx = nullptr;
+    int device = 0;  // copy of ctx->device (mic_plan_destroy does not touch the context)
     int filter = 0;
     bool persistent = false;
     std::vector<Job> jobs;     // caller order; out / px_shift / n_pages are set per run
@@ -726,13 +777,13 @@ struct mic_plan {
 static void plan_offsets(mic_plan *P) {
     P->off_layers = align_up(sizeof(Job) * P->jobs.size(), 64);
     P->off_f = align_up(P->off_layers + sizeof(Layer) * P->layers.size(), 64);
-    P->off_h = align_up(P->off_f + sizeof(RsMfma) * P->pt.fused.size(), 64);
+    P->off_h = align_up(P->off_f + sizeof(RsMarch) * P->pt.fused.size(), 64);
     P->off_v = align_up(P->off_h + sizeof(RsJob) * P->pt.h.size(), 64);
     P->total = align_up(P->off_v + sizeof(RsJob) * P->pt.v.size(), 64);
 }
 
 static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs, const mic_job *jobs,
-                      int filter, bool persistent, mic_plan *P) {
+                      int filter, bool persistent, hipStream_t stream, mic_plan *P) {
     if (n_jobs < 0 || n_atlases < 0 || (n_jobs > 0 && !jobs) || (n_atlases > 0 && !atlases))
         return fail(MIC_ERR_INVALID, "composite: bad arguments");
     if (filter != MIC_FILTER_LANCZOS && filter != MIC_FILTER_BILINEAR)
@@ -742,6 +793,7 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
         if (!atlases[a] || atlases[a]->ctx != ctx)
             return fail(MIC_ERR_INVALID, "atlas %d is null or belongs to another context", a);
     P->ctx = ctx;
+    P->device = ctx->device;
     P->filter = filter;
     P->persistent = persistent;
     P->jobs.assign((size_t)n_jobs, Job{});
@@ -752,7 +804,8 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
     std::vector<Pending> pending;  // layers whose src is a scratch offset, patched once scratch exists
     std::map<std::tuple<uint64_t, int, int, int>, size_t> dedup;  // (atlas uid, entry, w, h) -> plan
     size_t scratch_need = kPixelAlign;  // leading guard band
-    std::vector<bool> resampled_atlas((size_t)std::max(n_atlases, 1), false);  // atlases this call resamples from
+    // per atlas: (entry, plan) of the cutouts this call runs through the marching resample kernel
+    std::vector<std::vector<std::pair<int, size_t>>> planar_need((size_t)std::max(n_atlases, 1));
 
     for (int ji = 0; ji < n_jobs; ++ji) {
         const mic_job &J = jobs[ji];
@@ -789,9 +842,9 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
             const int64_t vx0 = std::max<int64_t>(x1, 0), vx1 = std::min<int64_t>(x1 + w, J.width);
             const int64_t vy0 = std::max<int64_t>(y1, 0), vy1 = std::min<int64_t>(y1 + h, J.height);
             if (vx0 >= vx1 || vy0 >= vy1) continue;
-            if (w > kMaxDim || h > kMaxDim || w * h >= ((int64_t)1 << 31))
+            if (w > kMaxDim || h > kMaxDim || w * h > kMaxLayerPx)
                 return fail(MIC_ERR_INVALID, "job %d placement %d: box %lldx%lld is too large (side <= %lld, "
-                            "area < 2^31 pixels)", ji, pi, (long long)w, (long long)h, (long long)kMaxDim);
+                            "area <= 2^30 - 8 pixels)", ji, pi, (long long)w, (long long)h, (long long)kMaxDim);
             Layer L{};
             L.dx = (int32_t)x1; L.dy = (int32_t)y1; L.w = (int32_t)w; L.h = (int32_t)h;
             st.layer_pixels += (uint64_t)(vx1 - vx0) * (vy1 - vy0);
@@ -810,21 +863,9 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                     ResizePlan rp{};
                     rp.src = reinterpret_cast<uint64_t>(A->blob) + E.offset;
                     rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
-                    if (int rc = choose_fused(ctx, &rp, filter)) return rc;
-                    if (rp.tx16 > 0) {
-                        // The planar copy pays for itself from the second resampling call on: an atlas
-                        // made for one call (composite() on a plain dict, a contact sheet) never builds it.
-                        if (!resampled_atlas[(size_t)Pl.atlas]) {
-                            resampled_atlas[(size_t)Pl.atlas] = true;
-                            if (!A->planar && (A->resample_calls++ >= 1 || persistent))  // a plan is made to be re-run
-                                if (int rc = atlas_ensure_planar(A)) return rc;
-                        }
-                        if (A->planar) {
-                            rp.planar_src = reinterpret_cast<uint64_t>(A->planar) + A->planar_off[(size_t)it->second];
-                            rp.planar_pitch = A->planar_pitch[(size_t)it->second];
-                        }
-                    }
-                    if (rp.tx16 == 0 && rp.dw != rp.sw && rp.dh != rp.sh) {
+                    if (int rc = choose_march(ctx, &rp, filter)) return rc;
+                    if (rp.march) planar_need[(size_t)Pl.atlas].push_back({it->second, plans.size()});
+                    if (!rp.march && rp.dw != rp.sw && rp.dh != rp.sh) {
                         rp.tmp_off = scratch_need;
                         scratch_need = align_up(scratch_need + (size_t)rp.dw * rp.sh * 4 + kGuard, kPixelAlign);
                     }
@@ -858,6 +899,18 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
     }
     for (const Pending &pd : pending)
         P->layers[pd.layer].src = reinterpret_cast<uint64_t>(scratch) + plans[pd.plan].dst_off;
+    for (int a = 0; a < n_atlases; ++a) {
+        if (planar_need[(size_t)a].empty()) continue;
+        const mic_atlas *A = atlases[a];
+        std::vector<int> entries;
+        for (const auto &ne : planar_need[(size_t)a]) entries.push_back(ne.first);
+        if (int rc = atlas_ensure_planar(A, entries, stream)) return rc;
+        for (const auto &ne : planar_need[(size_t)a]) {
+            plans[ne.second].planar_src = reinterpret_cast<uint64_t>(A->planar->dev) + A->planar_off[(size_t)ne.first];
+            plans[ne.second].planar_pitch = A->planar_pitch[(size_t)ne.first];
+        }
+        P->pt.frag_refs.push_back(A->planar);  // the pass tables point into it
+    }
     if (int rc = plan_passes(ctx, plans, filter, scratch, &P->pt)) return rc;
     plan_offsets(P);
     if (persistent && P->total > 0) {
@@ -867,7 +920,7 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                               sizeof(Layer) * P->layers.size(), hipMemcpyHostToDevice));
         if (!P->pt.fused.empty())
             HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_f, P->pt.fused.data(),
-                              sizeof(RsMfma) * P->pt.fused.size(), hipMemcpyHostToDevice));
+                              sizeof(RsMarch) * P->pt.fused.size(), hipMemcpyHostToDevice));
         if (!P->pt.h.empty())
             HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_h, P->pt.h.data(),
                               sizeof(RsJob) * P->pt.h.size(), hipMemcpyHostToDevice));
@@ -909,6 +962,9 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         }
         slot_tab->last_use = P->run_counter;
     }
+    // A cached table was validated (null / alignment / overlap checks below) when this exact set of
+    // output pointers was first seen; backgrounds and sizes are fixed at plan creation, so the same
+    // pointers give the same verdict and the checks are not repeated.
     const bool cached = slot_tab && !slot_tab->outs.empty();
 
     int class_end[3] = {0, 0, 0};
@@ -925,12 +981,27 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
             Job &d = P->ordered[(size_t)ji];
             if (outs) d.out = reinterpret_cast<uint64_t>(outs[ji]);
             if (!d.out) return fail(MIC_ERR_INVALID, "job %d: null output canvas", ji);
-            if (d.out == d.bg) return fail(MIC_ERR_INVALID, "job %d: output aliases the background", ji);
+            const uint64_t bytes = (uint64_t)d.W * d.H * 4;
+            // compositor.py:11 copies the background: a canvas that overlaps it anywhere would be read
+            // by one wave after another wave has written it
+            if (d.bg && d.out < d.bg + bytes && d.bg < d.out + bytes)
+                return fail(MIC_ERR_INVALID, "job %d: output overlaps the background", ji);
             if (d.out % 4 != 0) return fail(MIC_ERR_INVALID, "job %d: canvas pointers must be 4-byte aligned", ji);
             // 4 KiB pages aligned to absolute address: one workgroup per page (see mic_internal.h)
             d.px_shift = (int32_t)((d.out & 4095u) / 4);
             d.n_pages = (int32_t)(((uint64_t)d.W * d.H + d.px_shift + kPagePx - 1) / kPagePx);
             max_pages = std::max(max_pages, d.n_pages);
+        }
+        if (n_jobs > 1) {  // two canvases of one launch must not overlap (their pages are written concurrently)
+            std::vector<std::pair<uint64_t, uint64_t>> spans((size_t)n_jobs);
+            for (int ji = 0; ji < n_jobs; ++ji) {
+                const Job &d = P->ordered[(size_t)ji];
+                spans[(size_t)ji] = {d.out, d.out + (uint64_t)d.W * d.H * 4};
+            }
+            std::sort(spans.begin(), spans.end());
+            for (int ji = 1; ji < n_jobs; ++ji)
+                if (spans[(size_t)ji].first < spans[(size_t)ji - 1].second)
+                    return fail(MIC_ERR_INVALID, "two output canvases of the batch overlap");
         }
         pitch = (max_pages + 7) / 8 * 8;
         // sort the job table by kernel class (see launch_composite): 0 = aligned + solid opaque
@@ -965,7 +1036,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
             dp = static_cast<char *>(slot->dev);
             upload_dst = slot->dev;
             if (!P->layers.empty()) memcpy(hp + P->off_layers, P->layers.data(), sizeof(Layer) * P->layers.size());
-            if (!P->pt.fused.empty()) memcpy(hp + P->off_f, P->pt.fused.data(), sizeof(RsMfma) * P->pt.fused.size());
+            if (!P->pt.fused.empty()) memcpy(hp + P->off_f, P->pt.fused.data(), sizeof(RsMarch) * P->pt.fused.size());
             if (!P->pt.h.empty()) memcpy(hp + P->off_h, P->pt.h.data(), sizeof(RsJob) * P->pt.h.size());
             if (!P->pt.v.empty()) memcpy(hp + P->off_v, P->pt.v.data(), sizeof(RsJob) * P->pt.v.size());
         }
@@ -983,8 +1054,8 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     const bool prof = ctx->profiling && ctx->prof_calls < ctx->prof_max && (ctx->prof_seen++ % ctx->prof_every) == 0;
     hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], stream));
-    HIP_TRY(launch_resample_mfma(reinterpret_cast<const RsMfma *>(dp + P->off_f), (int)P->pt.fused.size(),
-                                  P->pt.fused_whole, P->pt.fused_lds, stream));
+    HIP_TRY(launch_resample_march(reinterpret_cast<const RsMarch *>(dp + P->off_f), (int)P->pt.fused.size(),
+                                   P->pt.fused_small, P->pt.lds_small, P->pt.lds_large, stream));
     HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + P->off_h), (int)P->pt.h.size(),
                               P->pt.max_h_out_w, P->pt.max_h_rows, stream));
     HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + P->off_v), (int)P->pt.v.size(),
@@ -1003,18 +1074,18 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
 
 extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,
                                    const mic_job *jobs, int filter, void *stream_v) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    CTX_ENTER(ctx);
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (int rc = adopt_stream(ctx, stream)) return rc;  // before the transient plan may regrow the arena
     mic_plan P;
-    if (int rc = plan_build(ctx, n_atlases, atlases, n_jobs, jobs, filter, /*persistent=*/false, &P)) return rc;
+    if (int rc = plan_build(ctx, n_atlases, atlases, n_jobs, jobs, filter, /*persistent=*/false, stream, &P)) return rc;
     return plan_submit(&P, nullptr, stream);
 }
 
 extern "C" int mic_render(mic_ctx *ctx, mic_atlas *atlas, const char *layout_json, size_t len, int32_t width,
                           int32_t height, const void *bg_dev, const uint8_t bg_rgba[4], int filter, void *out_dev,
                           void *stream_v, int32_t *n_placed) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    CTX_ENTER(ctx);
     if (!atlas || !layout_json || !out_dev || width <= 0 || height <= 0 || (!bg_dev && !bg_rgba))
         return fail(MIC_ERR_INVALID, "mic_render: bad arguments");
     if (atlas->ctx != ctx) return fail(MIC_ERR_INVALID, "mic_render: atlas belongs to another context");
@@ -1054,12 +1125,12 @@ extern "C" int mic_render(mic_ctx *ctx, mic_atlas *atlas, const char *layout_jso
 
 extern "C" int mic_plan_create(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,
                                const mic_job *jobs, int filter, mic_plan **out) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    CTX_ENTER(ctx);
     if (!out) return fail(MIC_ERR_INVALID, "mic_plan_create: null out");
     *out = nullptr;
     mic_plan *P = new (std::nothrow) mic_plan();
     if (!P) return fail(MIC_ERR_NOMEM, "out of host memory");
-    if (int rc = plan_build(ctx, n_atlases, atlases, n_jobs, jobs, filter, /*persistent=*/true, P)) {
+    if (int rc = plan_build(ctx, n_atlases, atlases, n_jobs, jobs, filter, /*persistent=*/true, ctx->last_stream, P)) {
         mic_plan_destroy(P);
         return rc;
     }
@@ -1069,14 +1140,14 @@ extern "C" int mic_plan_create(mic_ctx *ctx, int n_atlases, mic_atlas *const *at
 
 extern "C" int mic_plan_run(mic_plan *plan, void *const *outs, void *stream) {
     if (!plan) return fail(MIC_ERR_INVALID, "mic_plan_run: null plan");
-    if (int rc = ctx_enter(plan->ctx)) return rc;
+    CTX_ENTER(plan->ctx);
     return plan_submit(plan, outs, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mic_plan_destroy(mic_plan *plan) {
     if (!plan) return MIC_OK;
     if (plan->ctx) {
-        (void)hipSetDevice(plan->ctx->device);
+        (void)hipSetDevice(plan->device);
         if (plan->scratch || plan->tables_dev) (void)hipDeviceSynchronize();
     }
     if (plan->scratch) (void)hipFree(plan->scratch);
@@ -1095,6 +1166,7 @@ extern "C" int mic_plan_stats(const mic_plan *plan, mic_stats *out) {
 
 extern "C" int mic_last_stats(const mic_ctx *ctx, mic_stats *out) {
     if (!ctx || !out) return fail(MIC_ERR_INVALID, "mic_last_stats: null argument");
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     *out = ctx->stats;
     return MIC_OK;
 }
@@ -1102,7 +1174,7 @@ extern "C" int mic_last_stats(const mic_ctx *ctx, mic_stats *out) {
 extern "C" int mic_profile_begin(mic_ctx *ctx, int max_calls) { return mic_profile_begin_sampled(ctx, max_calls, 1); }
 
 extern "C" int mic_profile_begin_sampled(mic_ctx *ctx, int max_calls, int every) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    CTX_ENTER(ctx);
     if (max_calls <= 0 || max_calls > (1 << 20) || every <= 0)
         return fail(MIC_ERR_INVALID, "mic_profile_begin: bad max_calls / every");
     ctx->prof_every = every;
@@ -1119,7 +1191,7 @@ extern "C" int mic_profile_begin_sampled(mic_ctx *ctx, int max_calls, int every)
 }
 
 extern "C" int mic_profile_end(mic_ctx *ctx, void *stream, int *n_calls, double *composite_ms, double *resample_ms) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    CTX_ENTER(ctx);
     if (!n_calls || !composite_ms || !resample_ms) return fail(MIC_ERR_INVALID, "mic_profile_end: null argument");
     ctx->profiling = false;
     HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
@@ -1140,7 +1212,7 @@ extern "C" int mic_profile_end(mic_ctx *ctx, void *stream, int *n_calls, double 
 // ------------------------------------------------------------------------------------ resize
 extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int32_t src_h, void *dst_dev,
                           int32_t dst_w, int32_t dst_h, int filter, void *stream_v) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    CTX_ENTER(ctx);
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (!src_dev || !dst_dev) return fail(MIC_ERR_INVALID, "mic_resize: null image");
     if (src_w <= 0 || src_h <= 0 || dst_w <= 0 || dst_h <= 0 || src_w > kMaxDim || src_h > kMaxDim ||
@@ -1162,26 +1234,43 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
     rp.src = reinterpret_cast<uint64_t>(src_dev);
     rp.sw = src_w; rp.sh = src_h; rp.dw = dst_w; rp.dh = dst_h;
     rp.dst_ptr = reinterpret_cast<uint64_t>(dst_dev);
-    if (int rc = choose_fused(ctx, &rp, filter)) return rc;
+    if (int rc = choose_march(ctx, &rp, filter)) return rc;
+    // arena: the source's planar premultiplied copy (marching kernel) or the horizontal pass' output (two-pass fallback)
     size_t need = 0;
-    if (rp.tx16 == 0 && dst_w != src_w && dst_h != src_h) need = (size_t)dst_w * src_h * 4 + kGuard;
+    if (rp.march) {
+        rp.planar_pitch = (src_w + 15) / 16 * 16;
+        need = (size_t)4 * src_h * rp.planar_pitch;
+    } else if (dst_w != src_w && dst_h != src_h) {
+        need = (size_t)dst_w * src_h * 4 + kGuard;
+    }
     if (int rc = ensure_arena(ctx, need)) return rc;
+    if (rp.march) rp.planar_src = reinterpret_cast<uint64_t>(ctx->arena);
     PassTables pt;
     std::vector<ResizePlan> plans{rp};
     if (int rc = plan_passes(ctx, plans, filter, ctx->arena, &pt)) return rc;
-    const size_t off_v = 64, off_f = 128, total = 128 + sizeof(RsMfma) * std::max<size_t>(1, pt.fused.size());
+    const size_t off_v = 64, off_p = 128, off_f = 192;
+    const size_t total = off_f + sizeof(RsMarch) * std::max<size_t>(1, pt.fused.size());
     Slot *slot = nullptr;
     if (int rc = acquire_slot(ctx, total, &slot)) return rc;
     char *hp = static_cast<char *>(slot->host);
     if (!pt.h.empty()) memcpy(hp, pt.h.data(), sizeof(RsJob));
     if (!pt.v.empty()) memcpy(hp + off_v, pt.v.data(), sizeof(RsJob));
-    if (!pt.fused.empty()) memcpy(hp + off_f, pt.fused.data(), sizeof(RsMfma) * pt.fused.size());
+    if (rp.march) {
+        PlanarJob pj{};
+        pj.src = rp.src; pj.dst = rp.planar_src;
+        pj.w = src_w; pj.h = src_h; pj.pitch = rp.planar_pitch;
+        memcpy(hp + off_p, &pj, sizeof pj);
+    }
+    if (!pt.fused.empty()) memcpy(hp + off_f, pt.fused.data(), sizeof(RsMarch) * pt.fused.size());
     HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, total, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(slot->ev, stream));
     slot->pending = true;
     char *dp = static_cast<char *>(slot->dev);
-    HIP_TRY(launch_resample_mfma(reinterpret_cast<const RsMfma *>(dp + off_f), (int)pt.fused.size(),
-                                  pt.fused_whole, pt.fused_lds, stream));
+    if (rp.march)
+        HIP_TRY(launch_planarize(reinterpret_cast<const PlanarJob *>(dp + off_p), 1,
+                                 (int64_t)(rp.planar_pitch / 4) * src_h, stream));
+    HIP_TRY(launch_resample_march(reinterpret_cast<const RsMarch *>(dp + off_f), (int)pt.fused.size(),
+                                   pt.fused_small, pt.lds_small, pt.lds_large, stream));
     HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp), (int)pt.h.size(), pt.max_h_out_w,
                               pt.max_h_rows, stream));
     HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + off_v), (int)pt.v.size(), pt.max_v_out_w,
@@ -1192,7 +1281,7 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
 // ------------------------------------------------------------------------------------ background
 extern "C" int mic_median_rgb_dev(mic_ctx *ctx, const void *rgba_dev, int32_t width, int32_t height,
                                   void *rgba_out_dev, void *stream_v) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    CTX_ENTER(ctx);
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (!rgba_dev || !rgba_out_dev || width <= 0 || height <= 0)
         return fail(MIC_ERR_INVALID, "mic_median_rgb: bad arguments");
@@ -1205,7 +1294,7 @@ extern "C" int mic_median_rgb_dev(mic_ctx *ctx, const void *rgba_dev, int32_t wi
 extern "C" int mic_median_rgb(mic_ctx *ctx, const void *rgba_dev, int32_t width, int32_t height,
                               uint8_t out_rgb[3], void *stream_v) {
     if (!out_rgb) return fail(MIC_ERR_INVALID, "mic_median_rgb: null result");
-    if (!ctx) return fail(MIC_ERR_INVALID, "null context");
+    CTX_ENTER(ctx);  // held across the copy-back: median_host is context state
     uint32_t *res_dev = ctx->median_scratch + kMedianScratchWords;
     if (int rc = mic_median_rgb_dev(ctx, rgba_dev, width, height, res_dev, stream_v)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
@@ -1220,7 +1309,7 @@ extern "C" int mic_median_rgb(mic_ctx *ctx, const void *rgba_dev, int32_t width,
 
 extern "C" int mic_fill_solid(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height,
                               const uint8_t rgba[4], void *stream_v) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    CTX_ENTER(ctx);
     if (!out_dev || !rgba || width <= 0 || height <= 0) return fail(MIC_ERR_INVALID, "mic_fill_solid: bad arguments");
     const uint32_t c = (uint32_t)rgba[0] | ((uint32_t)rgba[1] << 8) | ((uint32_t)rgba[2] << 16) | ((uint32_t)rgba[3] << 24);
     HIP_TRY(launch_fill(out_dev, c, (size_t)width * height, static_cast<hipStream_t>(stream_v)));
@@ -1229,7 +1318,7 @@ extern "C" int mic_fill_solid(mic_ctx *ctx, void *out_dev, int32_t width, int32_
 
 extern "C" int mic_fill_gradient(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height, const uint8_t c1[3],
                                  const uint8_t c2[3], int vertical, void *stream_v) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    CTX_ENTER(ctx);
     if (!out_dev || !c1 || !c2 || width <= 0 || height <= 0 || width > kMaxDim || height > kMaxDim)
         return fail(MIC_ERR_INVALID, "mic_fill_gradient: bad arguments");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
@@ -1243,7 +1332,7 @@ extern "C" int mic_fill_gradient(mic_ctx *ctx, void *out_dev, int32_t width, int
 extern "C" int mic_draw_rect_outlines(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height, int32_t n,
                                       const int32_t *boxes, const uint8_t *colours, int32_t outline_width,
                                       void *stream_v) {
-    if (int rc = ctx_enter(ctx)) return rc;
+    CTX_ENTER(ctx);
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (!out_dev || width <= 0 || height <= 0 || width > kMaxDim || height > kMaxDim || n < 0 ||
         (n > 0 && (!boxes || !colours)) || outline_width < 0 || outline_width > kMaxDim)

@@ -71,38 +71,41 @@ struct alignas(16) RsJob {
 };
 static_assert(sizeof(RsJob) == 64, "RsJob layout");
 
-// One layer resized by the MFMA kernel: both axes in one launch, source planes and the 8-bit
-// intermediate in LDS.  Axis tables are the fragment form of resample_coeffs.h (AxisFrags); an axis
-// that keeps its size gets the identity table (one tap of weight 1.0: the pass Pillow skips).
-struct alignas(16) RsMfma {
-    uint64_t src, dst;
+// One layer resized by the marching MFMA kernel (kernels_resample.hip): both axes in one launch.  Axis
+// tables are the fragment form of resample_coeffs.h (AxisFrags); an axis that keeps its size gets the
+// identity table (one tap of weight 1.0: the pass Pillow skips).  Work units of a layer = `strips`
+// column strips (4 tiles of 16 output columns, one per wave) x `segs` segments of `seg_tiles` tiles of
+// 16 output rows; a workgroup marches one unit down the source in bands of 16 rows.
+struct alignas(16) RsMarch {
+    uint64_t src, dst;             // src: the cutout's planar premultiplied copy (4 planes of sh rows x planar_pitch)
     uint64_t hmeta, hbias, hfrag;  // horizontal axis: [xtiles][4] int32, [16 xtiles] int32, fragments
     uint64_t vmeta, vbias, vfrag;  // vertical axis
     int32_t sw, sh, dw, dh;
-    int32_t tx16, ty16;            // workgroup tile in units of 16 output samples
-    int32_t tiles_x, tiles_y;
-    int32_t pitch_c, pitch_r;      // bytes per row of a source plane / per column of an intermediate plane
-    int32_t rows16;                // rows of a source plane (multiple of 16): the whole window of a tile, or
-                                   // one band of it when the window is too tall for LDS (deep shrinks)
-    // A layer with more than kRsTilesPerEntry tiles takes several table entries (grid.y); workgroup
-    // bx of entry e works on tile ((bx + xcd_rot) & 7) * 4 n_entries + 4 e + (bx >> 3): workgroups
-    // are dealt round-robin over the 8 XCDs, so each XCD gets a contiguous band of the layer's tiles
-    // and neighbouring tiles (which share their source halo) share an L2.
+    int32_t planar_pitch;          // bytes per row of a source plane (a multiple of 16)
+    int32_t tiles_x, tiles_y;      // 16-sample tiles per axis
+    int32_t strips, segs, seg_tiles;
+    int32_t pitch_c;               // LDS bytes per row of a source band plane: what a strip's tiles can touch
+    int32_t ring16, pitch_r;       // ring of intermediate rows: 16-row slots (a power of two), bytes per column
+    // A layer with more than kRsUnitsPerEntry units takes several table entries (grid.y); workgroup
+    // bx of entry e works on unit ((bx + xcd_rot) & 7) * 4 n_entries + 4 e + (bx >> 3): workgroups
+    // are dealt round-robin over the 8 XCDs, so each XCD gets a contiguous run of the layer's units
+    // (x-fastest) and neighbouring strips (which share source columns and vertical taps) share an L2.
     int32_t entry, n_entries, xcd_rot;
-    // > 0: `src` is the atlas' planar premultiplied copy of the cutout (four planes of sh rows, this many
-    // bytes per row); 0: `src` is interleaved RGBA and is premultiplied while it is loaded.
-    int32_t planar_pitch;
-    int32_t pad;
 };
-static_assert(sizeof(RsMfma) == 128, "RsMfma layout");
-inline size_t rs_mfma_lds_bytes(int rows16, int pitch_c, int tx16, int pitch_r) {
-    return 4 * ((size_t)rows16 * pitch_c + (size_t)16 * tx16 * pitch_r) + 64;  // + slack for chunk over-reads
+static_assert(sizeof(RsMarch) == 128, "RsMarch layout");
+constexpr int kRsMaxSegTiles = 64;                 // tiles of 16 output rows per unit, at most
+inline size_t rs_march_lds_bytes(int pitch_c, int pitch_r) {
+    return 4 * ((size_t)16 * pitch_c + (size_t)64 * pitch_r) + 64;  // + slack for chunk over-reads
 }
-constexpr size_t kRsMfmaPreferredLds = 52 * 1024;  // three workgroups per CU (160 KB of LDS, 1 KB static each)
-constexpr size_t kRsMfmaMaxLds = 150 * 1024;       // last resort before the two-pass fallback
-// The launch is a (tiles per entry) x (entries) grid: a layer with more tiles takes several entries,
-// so that small layers do not pad the grid out to the largest layer's tile count.
-constexpr int kRsTilesPerEntry = 32;
+// Occupancy is what this kernel lives on (it is bound by vector issue): layers whose unit fits this much
+// LDS run 5 workgroups per CU; bigger windows (shrinks below ~1/2) go to a second launch.
+constexpr size_t kRsMarchSmallLds = 30000;  // + ~2 KB of static LDS: five per 160 KB
+constexpr size_t kRsMarchMergeLds = 38 * 1024;    // up to here one launch serves both classes (4 per CU)
+constexpr size_t kRsMarchMaxLds = 150 * 1024;      // last resort before the two-pass fallback
+constexpr int kRsUnitsPerEntry = 32;
+#ifndef MIC_RS_WAVES
+#define MIC_RS_WAVES 5  // waves per SIMD the marching kernel's register budget is set for
+#endif
 
 // ---- launchers (defined next to their kernels) -----------------------------------------------
 // The job table is sorted by kernel class; class_end[c] = one past the last job of class c for
@@ -122,8 +125,8 @@ struct alignas(16) PlanarJob {
 };
 static_assert(sizeof(PlanarJob) == 32, "PlanarJob layout");
 hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream);
-hipError_t launch_resample_mfma(const RsMfma *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes,
-                                hipStream_t stream);
+hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, int n_small, size_t lds_small, size_t lds_large,
+                                 hipStream_t stream);
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);
 // table_dev: scratch for max(W, H) <= 65535 colours (kGradientTableWords uint32)
 hipError_t launch_gradient(void *out, int W, int H, const uint8_t c1[3], const uint8_t c2[3], int vertical,

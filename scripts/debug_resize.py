@@ -1,0 +1,39 @@
+"""Differential check of mic_resize against the oracle with a mismatch map (debugging aid)."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402
+from image_transformation_amd import _native  # noqa: E402
+
+lib = _native.lib()
+ctx = _native.context(0)
+rng = np.random.default_rng(7)
+shapes = [((64, 64), (64, 48)), ((64, 64), (48, 64)), ((64, 64), (80, 80)), ((301, 203), (457, 311)),
+          ((457, 311), (301, 203)), ((1000, 800), (256, 205)), ((130, 70), (1301, 707))]
+if len(sys.argv) > 1:
+    a = [int(v) for v in sys.argv[1:5]]
+    shapes = [((a[0], a[1]), (a[2], a[3]))]
+for (sw, sh), (dw, dh) in shapes:
+    src = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
+    dev = torch.from_numpy(src).cuda()
+    dst = torch.zeros((dh, dw, 4), dtype=torch.uint8, device="cuda")
+    _native.check(lib.mic_resize(ctx.handle, ctypes.c_void_p(dev.data_ptr()), sw, sh, ctypes.c_void_p(dst.data_ptr()),
+                                 dw, dh, 0, ctypes.c_void_p(ctx.stream_ptr())))
+    got = dst.cpu().numpy()
+    want = oracle.resize(src, (dw, dh), 0)
+    bad = (got != want)
+    print(f"{sw}x{sh} -> {dw}x{dh}: mismatching bytes {int(bad.sum())} of {bad.size}; per channel {bad.sum(axis=(0, 1)).tolist()}")
+    if bad.any():
+        rows = np.nonzero(bad.any(axis=(1, 2)))[0]
+        cols = np.nonzero(bad.any(axis=(0, 2)))[0]
+        print("   rows", rows[:12].tolist(), "... n =", len(rows), " cols", cols[:12].tolist(), "... n =", len(cols))
+        y, x = rows[0], np.nonzero(bad[rows[0]].any(axis=1))[0][0]
+        print(f"   first at (x={x}, y={y}): got {got[y, x].tolist()} want {want[y, x].tolist()}")
+        d = np.abs(got.astype(int) - want.astype(int))
+        print("   max abs diff per channel", d.max(axis=(0, 1)).tolist())

@@ -105,3 +105,45 @@ def test_premultiply_packed_lanes_and_digit_split():
     d2 = (k1 - d1) >> 8
     assert np.array_equal(d0 + 256 * d1 + 65536 * d2, k)
     assert d2.min() >= -128 and d2.max() <= 127
+
+
+def test_unpremultiply_fma_round_to_nearest_exhaustive():
+    """kernels_resample.hip unpremultiply4 (marching kernel): per channel one fma and one
+    v_cvt_pk_u8_f32 (round to nearest even, saturating -- measured, profiles/r02_ubench_isa.txt):
+        sat8(rne(float32(c * F[a] - 0.5 + 2^-9))) == min(255, 255*c // a)   for 0 < a < 255,
+    and == c for a in {0, 255} with F = 1 (Convert.c rgba2rgbA copies those pixels)."""
+    c = np.arange(256, dtype=np.float64)
+    K = np.float64(np.float32(-0.5) + np.float32(2.0 ** -9))
+    assert K == -0.5 + 2.0 ** -9
+    for a in range(256):
+        if a in (0, 255):
+            F = np.float32(1.0)
+            want = np.arange(256)
+        else:
+            F = np.nextafter(np.float32(255.0) / np.float32(a), np.float32(np.inf))
+            want = np.minimum(255, (255 * np.arange(256)) // a)
+        # the fma rounds once: c * F is exact in float64 (8 x 24 bits), so is adding K (2^-9 granularity
+        # against |product| < 2^16: 25 + 24 bits < 53); float32() is then the fma's single rounding
+        t = (c * np.float64(F) + K).astype(np.float32)
+        got = np.clip(np.rint(t.astype(np.float64)), 0, 255).astype(np.int64)  # np.rint rounds half to even
+        assert np.array_equal(got, want), a
+
+
+def test_digit_chain_equals_the_full_sum():
+    """kernels_resample.hip tile4: the three signed-byte digits of the taps are chained through the
+    accumulator with two arithmetic shifts, acc = ((a0 + bias) >> 8 + a1) >> 8 + a2, out = sat8(acc >> 6),
+    instead of being recombined: equal to Pillow's clip8((bias + a0 + 256 a1 + 65536 a2) >> 22) for any
+    integers (nested floor divisions), checked here on random digit sums of the magnitudes a 64-tap window
+    of signed bytes can produce, bias = 2^21 + 128 * sum(taps)."""
+    rng = np.random.default_rng(5)
+    n = 2_000_000
+    lim = 64 * 128 * 128
+    a0 = rng.integers(-lim, lim + 1, n, dtype=np.int64)
+    a1 = rng.integers(-lim, lim + 1, n, dtype=np.int64)
+    a2 = rng.integers(-4 * 16384, 4 * 16384 + 1, n, dtype=np.int64)
+    bias = (1 << 21) + 128 * rng.integers((1 << 22) - 64, (1 << 22) + 65, n, dtype=np.int64)
+    chain = ((((a0 + bias) >> 8) + a1) >> 8) + a2
+    assert np.abs(a0 + bias).max() < 2 ** 31  # int32 accumulators never overflow
+    full = (bias + a0 + 256 * a1 + 65536 * a2) >> 22
+    assert np.array_equal(np.clip(chain >> 6, 0, 255), np.clip(full, 0, 255))
+    assert np.array_equal(chain >> 6, full)

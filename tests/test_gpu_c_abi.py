@@ -122,7 +122,7 @@ def test_raw_abi_rejects_bad_arguments(abi):
     job.width = 0
     assert lib.mic_composite_batch(ctx, 1, atl, 1, ctypes.byref(job), 0, _stream()) < 0 and b"canvas size" in lib.mic_last_error()
     job.width, job.bg_dev = 8, out.data_ptr()
-    assert lib.mic_composite_batch(ctx, 1, atl, 1, ctypes.byref(job), 0, _stream()) < 0 and b"aliases" in lib.mic_last_error()
+    assert lib.mic_composite_batch(ctx, 1, atl, 1, ctypes.byref(job), 0, _stream()) < 0 and b"overlaps the background" in lib.mic_last_error()
     job.bg_dev = None
     pl = (nat.Placement * 1)()
     pl[0].atlas, pl[0].object_id = 3, 1

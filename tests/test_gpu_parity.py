@@ -148,6 +148,41 @@ def test_resize_random_shapes_vs_oracle(gpu):
             assert np.array_equal(got, want), ((sw, sh), (dw, dh), filt, _maxdiff(got, want))
 
 
+def test_resize_transparent_margins_vs_oracle(gpu):
+    """Cutout-shaped sources (an opaque or soft blob inside wide transparent margins, like the reference's
+    bundles): the marching kernel skips the horizontal pass of source bands without a pixel of alpha > 0
+    and stores output tiles that only see such bands as transparent black -- including sources whose
+    transparent pixels carry colour (premultiplying zeroes it), a fully transparent source, and blobs
+    that start/end inside a 16-row band."""
+    import ctypes
+    import torch
+    from image_transformation_amd import _native
+    lib = _native.lib()
+    rng = np.random.default_rng(99)
+    cases_ = [((640, 480), (400, 300), (200, 150, 90, 60)), ((640, 480), (961, 719), (330, 250, 40, 200)),
+              ((500, 700), (250, 349), (250, 100, 200, 17)), ((300, 300), (300, 450), (150, 150, 10, 10)),
+              ((1200, 900), (300, 225), (600, 450, 250, 180)), ((257, 513), (500, 1000), (128, 40, 60, 33)),
+              ((400, 400), (200, 200), None)]
+    for (sw, sh), (dw, dh), blob in cases_:
+        src = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)  # colour everywhere, also under alpha 0
+        if blob is None:
+            src[:, :, 3] = 0
+        else:
+            cx, cy, rx, ry = blob
+            yy, xx = np.mgrid[0:sh, 0:sw]
+            inside = ((xx - cx) / rx) ** 2 + ((yy - cy) / ry) ** 2 <= 1.0
+            soft = rng.integers(1, 255, (sh, sw), dtype=np.uint8)
+            src[:, :, 3] = np.where(inside, np.where(rng.random((sh, sw)) < 0.7, 255, soft), 0)
+        dev = torch.from_numpy(src).to(gpu.torch_device)
+        for filt in (_native.LANCZOS, _native.BILINEAR):
+            dst = torch.empty((dh, dw, 4), dtype=torch.uint8, device=gpu.torch_device)
+            _native.check(lib.mic_resize(gpu.handle, ctypes.c_void_p(dev.data_ptr()), sw, sh,
+                                         ctypes.c_void_p(dst.data_ptr()), dw, dh, filt, ctypes.c_void_p(gpu.stream_ptr())))
+            want = oracle.resize(src, (dw, dh), filt)
+            got = dst.cpu().numpy()
+            assert np.array_equal(got, want), ((sw, sh), (dw, dh), blob, filt, _maxdiff(got, want))
+
+
 # ------------------------------------------------------------------------------------------ median / fill_solid
 def test_median_cases(gpu, golden_dir):
     from image_transformation_amd.background_resizing import _median_color_nontransparent
