@@ -7,10 +7,21 @@
 Workload (config.workload = "C3"): synthetic 3840x2160 canvas, 32 RGBA cutouts (binary alpha, as
 the reference's bundles), depth-2 row/column Flex-DSL layouts (seed 3).
 One step = one pass of the hot path over one batch: B distinct Flex layouts of the bundle are
-composited onto B canvases by ONE mic_composite_batch call per GPU (table upload + one kernel
-launch).  Timed region: placements + atlas resident on the device -> canvases complete in HBM
-(SURVEY.md section 8d); Flex box maths, atlas upload/broadcast and D2H are outside and are reported
-separately.  Output canvases rotate over > 256 MiB so the Infinity Cache cannot hold them.
+composited onto B canvases by ONE mic_plan_run call per GPU (one kernel launch).  Timed region:
+placements + atlas resident on the device -> canvases complete in HBM; Flex
+box maths, atlas upload/broadcast and D2H are outside and are reported separately.  Output canvases
+rotate over > 256 MiB so the Infinity Cache cannot hold them.
+
+The timed loop carries no instrumentation.  The kernel duration behind `roofline` comes from a
+SEPARATE pass of the same launches bracketed by HIP events on the launch stream (an event pair
+between two back-to-back launches leaves the GPU idle for a few microseconds, which would slow the
+very loop being timed).
+
+`roofline` reports the shared-atlas batch the metric is quoted on, split honestly: its cutout reads
+are re-reads of one 16 MB atlas that lives in L2 / the Infinity Cache, so `fabric` (algorithmic
+bytes over kernel time) is not a DRAM number; `dram` counts only what must cross the HBM pins
+(canvases written once + the atlas once).  `cold_inputs` is the leg in which the reads cannot be
+cached either: every canvas of the batch has an atlas of its own and the sets rotate over > 512 MB.
 
 N > 1: one process per GPU, variants sharded v -> GPU v mod N, the atlas is broadcast once over
 RCCL before the timed region, no collective on the data path ("scaling": "weak": B per GPU fixed).
@@ -21,6 +32,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -29,6 +41,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or platform.machine()
 
 
 def cpu_baseline(objs, placements, size, budget_s=12.0, max_reps=5000):
@@ -51,15 +74,44 @@ def cpu_baseline(objs, placements, size, budget_s=12.0, max_reps=5000):
     times.sort()
     med = times[len(times) // 2]
     return {"value": round(W * H / med / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "cpu": cpu_model(), "nproc": os.cpu_count(),
             "sample": f"{len(times)} reps of one 3840x2160/32-object Flex composite (layout 0), median "
-                      f"{med * 1e3:.1f} ms, oracle/mic_oracle.c single thread, nproc={os.cpu_count()}"}
+                      f"{med * 1e3:.1f} ms, oracle/mic_oracle.c single thread"}
+
+
+def _pillow_composite(bg, imgs, placements):
+    """This file's own restatement of the reference's loop (compositor.py:6-22); the reference's files
+    are not on the GPU box."""
+    from PIL import Image
+
+    canvas = bg.copy()
+    for p in placements:
+        obj = imgs.get(int(p["object_id"]))
+        if obj is None:
+            continue
+        x1, y1, x2, y2 = [int(v) for v in p["box"]]
+        o = obj.resize((max(1, x2 - x1), max(1, y2 - y1)), Image.LANCZOS)
+        canvas.alpha_composite(o, dest=(x1, y1))
+    return canvas
+
+
+def _median_time(fn, budget_s, max_reps):
+    fn()
+    times = []
+    t_all = time.perf_counter()
+    while (time.perf_counter() - t_all) < budget_s and len(times) < max_reps:
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    return times[len(times) // 2], len(times)
 
 
 def cpu_pillow(objs, placements, size, budget_s=5.0):
-    """when Pillow is installed on the box, the same composite through Pillow itself
-    (this file's own restatement of the reference's loop, compositor.py:6-22 -- the reference's files
-    are not here): the speed a user of the reference sees, and a cross-check of the port's number."""
+    """when Pillow is installed on the box, the same composite through Pillow itself:
+    the speed a user of the reference sees, and a cross-check of the port's number."""
     try:
+        import PIL
         from PIL import Image
     except ImportError:
         return None
@@ -69,30 +121,10 @@ def cpu_pillow(objs, placements, size, budget_s=5.0):
     W, H = size
     bg = Image.new("RGBA", (W, H), tuple(SOLID_BG))
     imgs = {k: Image.fromarray(np.ascontiguousarray(v), "RGBA") for k, v in objs.items()}
-
-    def run():
-        canvas = bg.copy()
-        for p in placements:
-            obj = imgs.get(int(p["object_id"]))
-            if obj is None:
-                continue
-            x1, y1, x2, y2 = [int(v) for v in p["box"]]
-            o = obj.resize((max(1, x2 - x1), max(1, y2 - y1)), Image.LANCZOS)
-            canvas.alpha_composite(o, dest=(x1, y1))
-        return canvas
-
-    run()
-    times = []
-    t_all = time.perf_counter()
-    while (time.perf_counter() - t_all) < budget_s and len(times) < 200:
-        t0 = time.perf_counter()
-        run()
-        times.append(time.perf_counter() - t0)
-    times.sort()
-    med = times[len(times) // 2]
-    import PIL
+    med, n = _median_time(lambda: _pillow_composite(bg, imgs, placements), budget_s, 200)
     return {"value": round(W * H / med / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "kind": "pillow",
-            "sample": f"{len(times)} reps of the same composite through Pillow {PIL.__version__} (resize + alpha_composite "
+            "ms_per_canvas": round(med * 1e3, 2),
+            "sample": f"{n} reps of the same composite through Pillow {PIL.__version__} (resize + alpha_composite "
                       f"loop), median {med * 1e3:.1f} ms"}
 
 
@@ -134,6 +166,44 @@ def cpu_baseline_threads(objs, placements, size, budget_s=8.0):
             "sample": f"{sum(done)} whole-canvas composites over {n_thr} threads in {el:.1f} s, one image per thread"}
 
 
+def bracketed(ctx, run, n):
+    """n launches bracketed by HIP events on the launch stream -> (composite ms, resample ms) per launch."""
+    import torch
+
+    ctx.profile_begin(n)
+    for k in range(n):
+        run(k)
+    torch.cuda.synchronize()
+    calls, c_ms, r_ms = ctx.profile_end()
+    return c_ms / max(calls, 1), r_ms / max(calls, 1)
+
+
+def plan_bytes(stats):
+    """Algorithmic bytes of one launch: every canvas written once + every visible cutout pixel read once."""
+    return 4 * stats["canvas_pixels"] + 4 * stats["layer_pixels"]
+
+
+def frac(nbytes, ms):
+    return round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None
+
+
+def batch_leg(ctx, atlas, canvases, rows, n_sets_bytes=320 << 20, reps=30):
+    """Kernel-only measurement of one composite batch: event-bracketed launches over rotating outputs."""
+    from image_transformation_amd.compositor import CompositeBatch
+
+    plan = CompositeBatch(atlas, canvases, rows)
+    st = plan.stats()
+    set_bytes = 4 * st["canvas_pixels"]
+    n_sets = max(2, -(-n_sets_bytes // max(set_bytes, 1)))
+    outs = [plan.alloc_outputs() for _ in range(n_sets)]
+    for k in range(3):
+        plan.run(outs[k % n_sets])
+    c_ms, _ = bracketed(ctx, lambda k: plan.run(outs[k % n_sets], check=False), reps)
+    b = plan_bytes(st)
+    return {"kernel_ms": round(c_ms, 4), "algorithmic_bytes": b, "frac_of_hbm_peak": frac(b, c_ms),
+            "Mpixels_per_s": round(st["canvas_pixels"] / (c_ms * 1e-3) / 1e6, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,18 +241,24 @@ def main():
 
     from image_transformation_amd import _native, flex, synthetic
     from image_transformation_amd.batch import broadcast_atlas, shard_indices
-    from image_transformation_amd.compositor import CompositeBatch, SolidCanvas, coerce_placements
+    from image_transformation_amd.compositor import Atlas, CompositeBatch, SolidCanvas, coerce_placements
 
     B = args.batch
     size, objs, layouts = synthetic.c3_workload(args.alpha, seed=3, n_layouts=B * world)
     W, H = size
 
-    # ---- atlas: packed on rank 0, broadcast once over RCCL, resident afterwards ----
+    # ---- atlas: packed on rank 0, broadcast once over RCCL, resident afterwards.  The first call also
+    # creates the HIP context, loads the code object and the library: reported as `first_ms`; what an upload
+    # (or broadcast) costs once the process is warm is measured by doing it again.
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     atlas = broadcast_atlas(objs if rank == 0 or world == 1 else None, src=0)
     torch.cuda.synchronize()
-    atlas_ms = (time.perf_counter() - t0) * 1e3
+    atlas_first_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    atlas = broadcast_atlas(objs if rank == 0 or world == 1 else None, src=0)
+    torch.cuda.synchronize()
+    atlas_warm_ms = (time.perf_counter() - t0) * 1e3
     ctx = atlas.ctx
 
     # ---- host Flex box maths (layout_json -> boxes), outside the timed region ----
@@ -198,7 +274,8 @@ def main():
     native_ms = (time.perf_counter() - t0) * 1e3 / max(len(mine), 1)
     assert all(nr is None or [tuple(r) for r in nr] == [tuple(r) for r in row] for nr, row in zip(native_rows, rows))
     box_px = sum(max(1, r[3] - r[1]) * max(1, r[4] - r[2]) for row in rows for r in row)
-    plan = CompositeBatch(atlas, [SolidCanvas(size, synthetic.SOLID_BG)] * len(mine), rows)
+    canvases = [SolidCanvas(size, synthetic.SOLID_BG)] * len(mine)
+    plan = CompositeBatch(atlas, canvases, rows)
 
     # rotating output sets, > 256 MiB in total
     set_bytes = B * W * H * 4
@@ -214,43 +291,56 @@ def main():
     torch.cuda.synchronize()
     stats = plan.stats()
 
-    # ---- timed region: exactly K steps ----
-    # HIP events around the composite kernel of every 8th step: an event pair between two back-to-back
-    # kernels leaves the GPU idle for a few microseconds, so bracketing every step would slow the very
-    # loop being timed; the sampled brackets still average >= 25 launches of the default run.
-    prof_every = 8 if args.steps >= 64 else 1
-    ctx.profile_begin(args.steps, every=prof_every)
+    # ---- timed region: exactly K steps, nothing else.  barrier + synchronize on both sides; the clock
+    # stops after this rank's own synchronize (the closing barrier is not this rank's work) ----
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         plan.run(out_sets[k % n_sets], check=False)
     torch.cuda.synchronize()
+    elapsed_rank = time.perf_counter() - t0
     barrier()
-    elapsed = time.perf_counter() - t0
-    n_prof, comp_ms, _ = ctx.profile_end()
+    elapsed, elapsed_min = elapsed_rank, elapsed_rank
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed_rank, -elapsed_rank], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, elapsed_min = float(t[0].item()), -float(t[1].item())
+
+    # ---- kernel duration: a separate, event-bracketed pass of the same launches ----
+    n_br = max(10, min(args.steps, 50))
+    kernel_ms, _ = bracketed(ctx, lambda k: plan.run(out_sets[k % n_sets], check=False), n_br)
+    if world > 1:
+        t = torch.tensor([kernel_ms, -kernel_ms], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kernel_ms_max, kernel_ms_min = float(t[0].item()), -float(t[1].item())
+    else:
+        kernel_ms_max = kernel_ms_min = kernel_ms
 
     # HBM bytes per launch from the PMC counters: measured separately with rocprofv3 (bench.py cannot
     # run under --pmc and time itself) and committed under profiles/; only quoted for the workload
     # it was measured on.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f)
-        if tj["workload"] == {"batch": B, "alpha": args.alpha, "canvas": [W, H], "objects": 32}:
-            traffic = tj["per_launch"]["hbm_bytes"]
+    traffic, traffic_src = None, None
+    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj["workload"] == {"batch": B, "alpha": args.alpha, "canvas": [W, H], "objects": 32}:
+                traffic = tj["per_launch"]["hbm_bytes"]
+                traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                break
 
     px_per_step = B * W * H * world
     value = px_per_step * args.steps / elapsed / 1e6
-    kernel_ms = comp_ms / max(n_prof, 1)
     # algorithmic bytes of ONE launch: every canvas written once + every visible cutout pixel read once
-    b_alg = 4 * stats["canvas_pixels"] + 4 * stats["layer_pixels"]
+    b_alg = plan_bytes(stats)
+    b_write, b_read = 4 * stats["canvas_pixels"], 4 * stats["layer_pixels"]
     achieved = b_alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    # what has to cross the HBM pins per launch: the canvases (written once, 531 MB per launch of a rotating
+    # > 1 GB set) and at most one pass over the shared atlas; the other B - 1 reads of every cutout are served
+    # by L2 / the Infinity Cache (FETCH_SIZE counts them: it sits on the L2's fabric side)
+    b_dram = b_write + min(b_read, atlas.nbytes)
 
     result = {
         "metric": "composited Mpixels/s at 4K canvas, 32 objects",
@@ -262,97 +352,30 @@ def main():
                    "canvases_per_step_per_gpu": B, "alpha": args.alpha, "parallelism": f"variants sharded v mod {world}",
                    "background": "solid, synthesised in-kernel", "filter": "identity scale (Flex pipeline)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "traffic_source": "profiles/r01_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE)"
-                     if traffic else None,
-                     "kernel": "composite_kernel", "kernel_ms": round(kernel_ms, 4), "kernel_launches_timed": n_prof,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "composite_kernel", "kernel_ms": round(kernel_ms, 4),
+                     "kernel_ms_source": f"{n_br} event-bracketed launches in a separate pass (not in the timed loop)",
                      "algorithmic_bytes_per_launch": b_alg,
-                     "read_frac_of_peak": round(4 * stats["layer_pixels"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                     if kernel_ms > 0 else None},
-        "atlas": {"bytes": atlas.nbytes, "upload_or_broadcast_ms": round(atlas_ms, 3)},
+                     "fabric": {"bytes": b_alg, "GBps": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                "note": "algorithmic bytes / kernel time; the cutout reads (a third of the bytes) are "
+                                        "re-reads of one shared 16 MB atlas served by L2 / Infinity Cache, so this is "
+                                        "memory-system (fabric) throughput, not DRAM bandwidth"},
+                     "dram": {"bytes": b_dram, "GBps": round(b_dram / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else None,
+                              "frac": frac(b_dram, kernel_ms),
+                              "note": "bytes that must cross the HBM pins: canvases written once + the atlas read once"},
+                     "read_frac_of_peak": frac(b_read, kernel_ms)},
+        "atlas": {"bytes": atlas.nbytes, "first_ms": round(atlas_first_ms, 3), "warm_upload_or_broadcast_ms": round(atlas_warm_ms, 3),
+                  "note": "first_ms includes HIP context creation and code-object load"},
         "host_layout_ms_per_image": {"python_mirror": round(layout_ms, 3),
                                      "native_mic_flex_place": round(native_ms, 4) if all(r is not None for r in native_rows) else None},
         "box_area_Mpixels_per_s": round(box_px * world * args.steps / elapsed / 1e6, 1),
     }
+    if world > 1:
+        result["per_rank"] = {"timed_region_s_max": round(elapsed, 6), "timed_region_s_min": round(elapsed_min, 6),
+                              "kernel_ms_max": round(kernel_ms_max, 4), "kernel_ms_min": round(kernel_ms_min, 4)}
 
     if rank == 0 and world == 1 and not args.no_extras:
-        # single-canvas launches (latency view of the same workload)
-        one = CompositeBatch(atlas, [SolidCanvas(size, synthetic.SOLID_BG)], rows[:1])
-        outs1 = [one.alloc_outputs() for _ in range(12)]
-        for k in range(10):
-            one.run(outs1[k % 12])
-        ctx.profile_begin(100)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(100):
-            one.run(outs1[k % 12])
-        torch.cuda.synchronize()
-        e1 = time.perf_counter() - t0
-        n1, c1, _ = ctx.profile_end()
-        s1 = one.stats()
-        result["single_canvas"] = {"ms_per_canvas_wall": round(e1 / 100 * 1e3, 4), "kernel_ms": round(c1 / n1, 4),
-                                   "Mpixels_per_s": round(W * H * 100 / e1 / 1e6, 1),
-                                   "roofline_frac": round((4 * s1["canvas_pixels"] + 4 * s1["layer_pixels"]) /
-                                                          (c1 / n1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        # placements mode (direct composite() callers): Pillow-exact LANCZOS resample + overlaps
-        psize, pobjs, ppl = synthetic.placements_workload(W, H, 32, 3, "soft")
-        from image_transformation_amd.compositor import Atlas
-        patlas = Atlas(pobjs)
-        pplan = CompositeBatch(patlas, [SolidCanvas(psize, synthetic.SOLID_BG)], [coerce_placements(patlas, ppl)])
-        pout = pplan.alloc_outputs()
-        pplan.run(pout)
-        torch.cuda.synchronize()
-        ctx.profile_begin(10)
-        t0 = time.perf_counter()
-        for _ in range(10):
-            pplan.run(pout)
-        torch.cuda.synchronize()
-        e2 = time.perf_counter() - t0
-        n2, c2, r2 = ctx.profile_end()
-        ps = pplan.stats()
-        rs_bytes = 4 * (ps["source_pixels"] + sum(max(1, p["box"][2] - p["box"][0]) * max(1, p["box"][3] - p["box"][1])
-                                                  for p in ppl))  # every cutout read once + every resampled pixel written once
-        result["placements_mode_lanczos"] = {"ms_per_canvas_wall": round(e2 / 10 * 1e3, 3),
-                                             "resample_ms": round(r2 / n2, 3), "composite_ms": round(c2 / n2, 4),
-                                             "Mpixels_per_s": round(W * H * 10 / e2 / 1e6, 1),
-                                             "resample_roofline": {"bound": "valu (instruction issue), not hbm",
-                                                                   "algorithmic_bytes": rs_bytes,
-                                                                   "achieved_GBps": round(rs_bytes / (r2 / n2 * 1e-3) / 1e9, 1),
-                                                                   "frac_of_hbm_peak": round(rs_bytes / (r2 / n2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
-
-        # PCIe-inclusive step: job-table upload + composite + D2H of every canvas into pinned memory
-        # (SURVEY 8d's end-to-end figure; never `value`)
-        host = [torch.empty((H, W, 4), dtype=torch.uint8, pin_memory=True) for _ in range(len(rows))]
-        for _ in range(2):
-            for h, o in zip(host, plan.run(out_sets[0])):
-                h.copy_(o, non_blocking=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(5):
-            for h, o in zip(host, plan.run(out_sets[k % n_sets])):
-                h.copy_(o, non_blocking=True)
-        torch.cuda.synchronize()
-        e3 = (time.perf_counter() - t0) / 5
-        result["pcie_inclusive"] = {"ms_per_step": round(e3 * 1e3, 3), "Mpixels_per_s": round(B * W * H / e3 / 1e6, 1),
-                                    "d2h_GBps": round(B * W * H * 4 / e3 / 1e9, 1)}
-        del host
-        # background synthesis on the same canvas size: median colour of a 4K RGBA image + solid fill
-        import ctypes
-        P = ctypes.c_void_p
-        lib = _native.lib()
-        img = torch.randint(0, 256, (H, W, 4), dtype=torch.uint8, device=dev)
-        res = torch.empty(4, dtype=torch.uint8, device=dev)
-        sp = P(ctx.stream_ptr())
-        for name, fn in (("median_4k_noise_us", lambda: lib.mic_median_rgb_dev(ctx.handle, P(img.data_ptr()), W, H, P(res.data_ptr()), sp)),):
-            for _ in range(3):
-                _native.check(fn())
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(50):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            result[name] = round(e0.elapsed_time(e1) / 50 * 1e3, 1)
+        extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_sets, n_sets, size, dev)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(objs, placements[0], size)
@@ -365,6 +388,169 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_sets, n_sets, size, dev):
+    """Secondary measurements (N = 1 only): everything the headline line does not show."""
+    import ctypes
+
+    import numpy as np
+    import torch
+    from image_transformation_amd import _native, flex, synthetic
+    from image_transformation_amd.compositor import (Atlas, CompositeBatch, ObjectImages, SolidCanvas, coerce_placements,
+                                                     composite, render)
+
+    W, H = size
+    B = args.batch
+    solid = SolidCanvas(size, synthetic.SOLID_BG)
+
+    # ---- cold inputs: one atlas per canvas of the batch, two such sets alternating with the output sets, so
+    # that neither the reads (2 x 256 MB of atlases) nor the writes (> 1 GB of canvases) can live in a cache:
+    # every byte of `roofline` crosses the HBM pins
+    t0 = time.perf_counter()
+    cold_sets = []
+    for s in range(2):
+        atl = [Atlas(objs) for _ in range(B)]
+        cold_sets.append(CompositeBatch(atl, [solid] * B, rows, atlas_of=list(range(B))))
+    torch.cuda.synchronize()
+    for k in range(4):
+        cold_sets[k % 2].run(out_sets[k % n_sets])
+    c_ms, _ = bracketed(ctx, lambda k: cold_sets[k % 2].run(out_sets[k % n_sets], check=False), 30)
+    st = cold_sets[0].stats()
+    b = plan_bytes(st)
+    result["cold_inputs"] = {
+        "what": f"{B} canvases per launch, each reading an atlas of its own ({B} x {atlas.nbytes >> 20} MB), two such sets "
+                "and the output sets alternating: inputs 2 x 256 MB + outputs > 1 GB never re-used within 256 MB of traffic",
+        "kernel_ms": round(c_ms, 4), "Mpixels_per_s": round(st["canvas_pixels"] / (c_ms * 1e-3) / 1e6, 1),
+        "roofline": {"bound": "hbm", "achieved": round(b / (c_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": frac(b, c_ms), "algorithmic_bytes_per_launch": b,
+                     "read_frac_of_peak": frac(4 * st["layer_pixels"], c_ms)}}
+    del cold_sets
+
+    # ---- single-canvas launches: the reference's own call shape (one composite() per call)
+    one = CompositeBatch(atlas, [solid], rows[:1])
+    outs1 = [one.alloc_outputs() for _ in range(12)]
+    for k in range(10):
+        one.run(outs1[k % 12])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(100):
+        one.run(outs1[k % 12], check=False)
+    torch.cuda.synchronize()
+    e1 = time.perf_counter() - t0
+    c1, _ = bracketed(ctx, lambda k: one.run(outs1[k % 12], check=False), 50)
+    s1 = one.stats()
+    result["single_canvas"] = {"ms_per_canvas_wall": round(e1 / 100 * 1e3, 4), "kernel_ms": round(c1, 4),
+                               "Mpixels_per_s": round(W * H * 100 / e1 / 1e6, 1),
+                               "roofline_frac": frac(plan_bytes(s1), c1)}
+    del one, outs1
+
+    # ---- the hard classes, kernel-only, 16-canvas batches: soft alpha, a width that is not a multiple of 4,
+    # and all four C4 canvas classes in one launch
+    _, sobjs, slayouts = synthetic.c3_workload("soft", seed=3, n_layouts=B)
+    satlas = Atlas(sobjs)
+    srows = [coerce_placements(satlas, flex.layout_to_placements(l, satlas, size)) for l in slayouts]
+    result["soft_alpha_batch"] = batch_leg(ctx, satlas, [solid] * B, srows)
+    c4objs, variants = synthetic.c4_workload(args.alpha, seed=4, n_variants=64)
+    c4atlas = Atlas(c4objs)
+    wide = [v for v in variants if v[0][0] % 4 != 0][:B]
+    result["unaligned_width_batch"] = dict(
+        canvas=list(wide[0][0]),
+        **batch_leg(ctx, c4atlas, [SolidCanvas(s, synthetic.SOLID_BG) for s, _ in wide],
+                    [coerce_placements(c4atlas, flex.layout_to_placements(l, c4atlas, s)) for s, l in wide]))
+    mixed = variants[:B]  # ratios cycle 9:16, 1:1, 16:9, 21:9: four of each class
+    result["mixed_c4_batch"] = dict(
+        canvases=sorted({tuple(s) for s, _ in mixed}),
+        **batch_leg(ctx, c4atlas, [SolidCanvas(s, synthetic.SOLID_BG) for s, _ in mixed],
+                    [coerce_placements(c4atlas, flex.layout_to_placements(l, c4atlas, s)) for s, l in mixed]))
+    del satlas, c4atlas
+
+    # ---- placements mode (direct composite() callers): Pillow-exact LANCZOS resample + overlaps
+    psize, pobjs, ppl = synthetic.placements_workload(W, H, 32, 3, "soft")
+    patlas = Atlas(pobjs)
+    pplan = CompositeBatch(patlas, [SolidCanvas(psize, synthetic.SOLID_BG)], [coerce_placements(patlas, ppl)])
+    pout = pplan.alloc_outputs()
+    for _ in range(3):
+        pplan.run(pout)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        pplan.run(pout, check=False)
+    torch.cuda.synchronize()
+    e2 = time.perf_counter() - t0
+    c2, r2 = bracketed(ctx, lambda k: pplan.run(pout, check=False), 20)
+    ps = pplan.stats()
+    rs_bytes = 4 * (ps["source_pixels"] + sum(max(1, p["box"][2] - p["box"][0]) * max(1, p["box"][3] - p["box"][1])
+                                              for p in ppl))  # every cutout read once + every resampled pixel written once
+    result["placements_mode_lanczos"] = {
+        "ms_per_canvas_wall": round(e2 / 10 * 1e3, 3), "resample_ms": round(r2, 4), "composite_ms": round(c2, 4),
+        "Mpixels_per_s": round(W * H * 10 / e2 / 1e6, 1),
+        "composite_roofline_frac": frac(plan_bytes(ps), c2),
+        "resample_roofline": {"bound": "instruction issue (VALU + scalar), not hbm: profiles/r02_resample_experiments.txt",
+                              "algorithmic_bytes": rs_bytes, "achieved_GBps": round(rs_bytes / (r2 * 1e-3) / 1e9, 1),
+                              "frac_of_hbm_peak": frac(rs_bytes, r2)}}
+    del pplan, patlas
+
+    # ---- PCIe-inclusive step: job-table upload + composite + D2H of every canvas into pinned memory
+    # (SURVEY 8d's end-to-end figure; never `value`)
+    host = [torch.empty((H, W, 4), dtype=torch.uint8, pin_memory=True) for _ in range(len(rows))]
+    for _ in range(2):
+        for h, o in zip(host, plan.run(out_sets[0])):
+            h.copy_(o, non_blocking=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(5):
+        for h, o in zip(host, plan.run(out_sets[k % n_sets])):
+            h.copy_(o, non_blocking=True)
+    torch.cuda.synchronize()
+    e3 = (time.perf_counter() - t0) / 5
+    result["pcie_inclusive"] = {"ms_per_step": round(e3 * 1e3, 3), "Mpixels_per_s": round(B * W * H / e3 / 1e6, 1),
+                                "d2h_GBps": round(B * W * H * 4 / e3 / 1e9, 1)}
+    del host
+
+    # ---- the PIL-level drop-in (what a user of the reference calls), beside cpu_pillow: PIL in, PIL out,
+    # host transfers and Python included, one 4K canvas per call
+    try:
+        from PIL import Image
+
+        imgs = ObjectImages({k: Image.fromarray(np.ascontiguousarray(v), "RGBA") for k, v in objs.items()})
+        bg_solid = Image.new("RGBA", size, tuple(synthetic.SOLID_BG))
+        noise = np.random.default_rng(1).integers(0, 256, (H, W, 4), dtype=np.uint8)
+        noise[:, :, 3] = 255
+        bg_image = Image.fromarray(noise, "RGBA")
+        t_solid, _ = _median_time(lambda: composite(bg_solid, imgs, placements[0]), 3.0, 100)
+        t_image, _ = _median_time(lambda: composite(bg_image, imgs, placements[0]), 3.0, 100)
+        t_render, _ = _median_time(lambda: render(layouts[0], imgs, solid), 3.0, 100)
+        result["pil_dropin"] = {
+            "composite_pil_solid_bg_ms": round(t_solid * 1e3, 3), "composite_pil_image_bg_ms": round(t_image * 1e3, 3),
+            "render_solidcanvas_to_pil_ms": round(t_render * 1e3, 3),
+            "note": "composite(PIL bg, {id: PIL}, placements) -> PIL and render(layout, ObjectImages, SolidCanvas) -> PIL "
+                    "at 3840x2160 / 32 objects, median wall time per call, cutouts resident (second call on)"}
+    except ImportError:
+        result["pil_dropin"] = None
+
+    # ---- background synthesis: median colour of RGBA images (noise: every bin populated)
+    P = ctypes.c_void_p
+    lib = _native.lib()
+    res = torch.empty(4, dtype=torch.uint8, device=dev)
+    sp = P(ctx.stream_ptr())
+    med = {}
+    for label, (mw, mh) in (("492x492", (492, 492)), ("1080p", (1920, 1080)), ("4k", (W, H)), ("8k", (7680, 4320))):
+        img = torch.randint(0, 256, (mh, mw, 4), dtype=torch.uint8, device=dev)
+        fn = lambda: lib.mic_median_rgb_dev(ctx.handle, P(img.data_ptr()), mw, mh, P(res.data_ptr()), sp)  # noqa: E731
+        for _ in range(3):
+            _native.check(fn())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 50 * 1e3
+        med[label] = {"us": round(us, 1), "frac_of_hbm_peak": round(4 * mw * mh / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+        del img
+    result["median_noise"] = med
+    result["median_4k_noise_us"] = med["4k"]["us"]
 
 
 if __name__ == "__main__":

@@ -101,13 +101,18 @@ SYMBOLS = {
 
 def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     """dlopen libmic.so and declare every prototype.  Needs no GPU (symbols only)."""
-    if not os.path.exists(path) and path == LIB_PATH:
-        # not a fallback: the HIP library itself is (re)built when hipcc is at hand (a fresh checkout)
+    if path == LIB_PATH and not os.environ.get("MIC_LIB"):
+        # not a fallback: the HIP library itself is (re)built when it is missing or older than its sources and
+        # hipcc is at hand (build() is a no-op otherwise); without hipcc a stale library is reported, not used silently
+        from . import build as _build
         try:
-            from . import build as _build
-            _build.build()
-        except Exception:
-            pass
+            if _build._stale():
+                _build.build()
+        except Exception as exc:  # no hipcc on this machine, or the build failed
+            if os.path.exists(path):
+                import warnings
+                warnings.warn(f"{path} is older than its sources and could not be rebuilt ({exc}); "
+                              "run `python -m image_transformation_amd.build`", RuntimeWarning)
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} is missing: build it with `python -m image_transformation_amd.build` "
@@ -194,10 +199,11 @@ def context(device: Optional[int] = None) -> Context:
                                "(there is no CPU fallback)")
         device = torch.cuda.current_device()
     device = int(device)
-    with _lock:
-        ctx = _contexts.get(device)
+    ctx = _contexts.get(device)
     if ctx is None:
-        ctx = Context(device)
-        with _lock:
-            ctx = _contexts.setdefault(device, ctx)
+        lib()  # (takes _lock itself)
+        with _lock:  # created under the lock: two threads racing here must not make (and leak) two contexts
+            ctx = _contexts.get(device)
+            if ctx is None:
+                ctx = _contexts[device] = Context(device)
     return ctx

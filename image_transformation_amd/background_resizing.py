@@ -16,7 +16,7 @@ import numpy as np
 from PIL import Image
 
 from . import _native
-from .compositor import SolidCanvas, _image_to_array, _to_pil, _upload, open_rgba
+from .compositor import SolidCanvas, _to_pil, _upload, open_rgba
 
 _P = ctypes.c_void_p
 
@@ -37,10 +37,11 @@ def median_color_device(rgba_dev, ctx: Optional[_native.Context] = None) -> Tupl
 
 def _median_color_nontransparent(img_rgba: Image.Image) -> Tuple[int, int, int]:
     ctx = _native.context()
-    arr = _image_to_array(img_rgba)
-    if arr.size == 0:
+    if img_rgba.mode != "RGBA":
+        raise ValueError("image has wrong mode")
+    if img_rgba.size[0] * img_rgba.size[1] == 0:
         raise ValueError("cannot take the median of an empty image")
-    return median_color_device(_upload(arr, ctx), ctx)
+    return median_color_device(_upload(img_rgba, ctx), ctx)
 
 
 def solid_canvas(background_path: str, canvas_size: Tuple[int, int]) -> SolidCanvas:
@@ -78,9 +79,9 @@ def _edge_strip_median_colors(img: Image.Image, strip_px: int = 8):
     """(left, right, top, bottom) median colours of the image's edge strips
     (background_resizing.py:36-57); each via the histogram-median kernel."""
     ctx = _native.context()
-    arr = _image_to_array(img.convert("RGBA"))
-    dev = _upload(arr, ctx)
-    h, w = arr.shape[0], arr.shape[1]
+    rgba = img if img.mode == "RGBA" else img.convert("RGBA")
+    dev = _upload(rgba, ctx)
+    w, h = rgba.size
     strips = (dev[:, :min(strip_px, w)], dev[:, max(0, w - strip_px):],
               dev[:min(strip_px, h)], dev[max(0, h - strip_px):])
     return tuple(median_color_device(s.contiguous(), ctx) for s in strips)

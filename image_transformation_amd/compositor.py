@@ -20,7 +20,9 @@ from typing import Any, Dict, Iterable, List, Mapping, Optional, Sequence, Tuple
 import numpy as np
 from PIL import Image
 
-from . import _native
+import threading
+
+from . import _native, _pilmem
 from ._native import LANCZOS, BILINEAR, Placement, Job  # noqa: F401
 from . import flex
 
@@ -42,6 +44,7 @@ class _DecodeCache:
     is decoded once per process.  Entries are returned as copies (callers may mutate PIL images)."""
     _items: "Dict[Tuple[str, int, int], Image.Image]" = {}
     _bytes = 0
+    _lock = threading.Lock()  # the reference's Streamlit app runs every session on its own thread
     LIMIT = 512 << 20
 
     @classmethod
@@ -49,15 +52,17 @@ class _DecodeCache:
         p = os.fspath(path)
         st = os.stat(p)  # raises FileNotFoundError like Image.open
         key = (os.path.abspath(p), st.st_mtime_ns, st.st_size)
-        im = cls._items.get(key)
+        with cls._lock:
+            im = cls._items.get(key)
         if im is None:
             im = Image.open(p).convert("RGBA")
             nbytes = im.size[0] * im.size[1] * 4
-            if cls._bytes + nbytes > cls.LIMIT:
-                cls._items.clear()
-                cls._bytes = 0
-            cls._items[key] = im
-            cls._bytes += nbytes
+            with cls._lock:
+                if cls._bytes + nbytes > cls.LIMIT:
+                    cls._items.clear()
+                    cls._bytes = 0
+                cls._items[key] = im
+                cls._bytes += nbytes
         return im.copy()
 
 
@@ -92,43 +97,48 @@ def _device_guard(ctx: _native.Context):
     return _NO_GUARD if torch.cuda.current_device() == ctx.device else torch.cuda.device(ctx.torch_device)
 
 
-class _Pinned:
-    """Per-process pinned host buffers for the PIL-level entry points: a pageable 33 MB transfer is
-    staged by the runtime at a few GB/s, a pinned one moves at PCIe speed.  One buffer per direction,
-    grown on demand; contents are only live between a copy and the synchronise that follows it."""
-    _bufs: Dict[str, Any] = {}
-
-    @classmethod
-    def get(cls, key: str, nbytes: int):
-        torch = _torch()
-        buf = cls._bufs.get(key)
-        if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, pin_memory=True)
-            cls._bufs[key] = buf
-        return buf[:nbytes]
+def _pinned(nbytes: int):
+    """A pinned host buffer of its own for one transfer.  torch's caching host allocator hands a freed
+    block back without a new hipHostMalloc (microseconds after the first call of a size) and keeps a
+    block alive until the copies enqueued on it have run, so concurrent callers never share a buffer --
+    the per-process pair of staging buffers this replaces was not safe for two threads."""
+    return _torch().empty(max(int(nbytes), 1), dtype=_torch().uint8, pin_memory=True)
 
 
-def _upload(arr: np.ndarray, ctx: _native.Context):
-    """Host (H, W, 4) uint8 -> device tensor, through the pinned upload buffer."""
+def _upload(arr, ctx: _native.Context):
+    """Host RGBA pixels -> device (H, W, 4) uint8 tensor through a pinned buffer.  `arr` is a PIL RGBA image
+    (its rows are memmove'd out of Pillow's own memory: no Image.tobytes() pass) or an (H, W, 4) array."""
     torch = _torch()
-    arr = np.ascontiguousarray(arr)
-    n = arr.size
-    pin = _Pinned.get("h2d", n)
-    pin.numpy()[:] = arr.reshape(-1)
-    dev = torch.empty(arr.shape, dtype=torch.uint8, device=ctx.torch_device)
-    dev.view(-1).copy_(pin, non_blocking=True)
-    torch.cuda.current_stream(ctx.torch_device).synchronize()  # the pinned buffer is reused by the next call
+    if isinstance(arr, Image.Image):
+        if arr.mode != "RGBA":
+            raise ValueError("image has wrong mode")  # what Pillow's core.alpha_composite raises
+        W, H = arr.size
+        pin = _pinned(H * W * 4)
+        if not _pilmem.copy_to(arr, pin.data_ptr()):
+            pin.numpy()[:] = np.asarray(arr, dtype=np.uint8).reshape(-1)
+        shape = (H, W, 4)
+    else:
+        arr = np.ascontiguousarray(arr)
+        pin = _pinned(arr.size)
+        pin.numpy()[:arr.size] = arr.reshape(-1)
+        shape = arr.shape
+    n = shape[0] * shape[1] * 4 if len(shape) == 3 else int(np.prod(shape))
+    dev = torch.empty(shape, dtype=torch.uint8, device=ctx.torch_device)
+    dev.view(-1).copy_(pin[:n], non_blocking=True)  # the allocator keeps `pin` alive until the copy has run
     return dev
 
 
 def _to_pil(canvas_dev) -> Image.Image:
-    """Device (H, W, 4) uint8 -> a PIL RGBA image that owns its pixels."""
+    """Device (H, W, 4) uint8 -> a PIL RGBA image over a pinned host buffer of its own (no second host
+    copy: Image.frombuffer shares the memory and marks the image read-only, so Pillow copies it by itself
+    should the caller ever modify the image in place; .save(), which is what the reference does with the
+    result (macro_placement_test.py:1513), reads it as it is).  The buffer lives as long as the image."""
     torch = _torch()
     h, w = int(canvas_dev.shape[0]), int(canvas_dev.shape[1])
-    pin = _Pinned.get("d2h", h * w * 4)
+    pin = _pinned(h * w * 4)
     pin.copy_(canvas_dev.reshape(-1), non_blocking=True)
     torch.cuda.current_stream(canvas_dev.device).synchronize()
-    return Image.frombuffer("RGBA", (w, h), pin.numpy(), "raw", "RGBA", 0, 1).copy()
+    return Image.frombuffer("RGBA", (w, h), pin.numpy(), "raw", "RGBA", 0, 1)
 
 
 class _Entry:
@@ -146,15 +156,20 @@ def pack_blob(objects: Mapping[int, Any], pin: bool = False):
     ids: List[int] = []
     arrs: List[np.ndarray] = []
     for oid, im in objects.items():
-        arr = _image_to_array(im) if isinstance(im, Image.Image) else np.ascontiguousarray(im, np.uint8)
-        if arr.ndim != 3 or arr.shape[2] != 4:
-            raise ValueError("image has wrong mode")
+        if isinstance(im, Image.Image):
+            if im.mode != "RGBA":
+                raise ValueError("image has wrong mode")
+            arr = im  # copied row by row straight out of Pillow's memory below
+        else:
+            arr = np.ascontiguousarray(im, np.uint8)
+            if arr.ndim != 3 or arr.shape[2] != 4:
+                raise ValueError("image has wrong mode")
         ids.append(int(oid))
         arrs.append(arr)
     n = len(ids)
     ids_a = np.asarray(ids, np.int32)
-    ws = np.asarray([a.shape[1] for a in arrs], np.int32)
-    hs = np.asarray([a.shape[0] for a in arrs], np.int32)
+    ws = np.asarray([a.size[0] if isinstance(a, Image.Image) else a.shape[1] for a in arrs], np.int32)
+    hs = np.asarray([a.size[1] if isinstance(a, Image.Image) else a.shape[0] for a in arrs], np.int32)
     nbytes = ctypes.c_size_t()
     _native.check(lib.mic_atlas_blob_size(n, _i32p(ws), _i32p(hs), ctypes.byref(nbytes)))
     torch = _torch()
@@ -165,7 +180,12 @@ def pack_blob(objects: Mapping[int, Any], pin: bool = False):
     _native.check(lib.mic_atlas_blob_layout(n, _i32p(ids_a), _i32p(ws), _i32p(hs), _P(host_np.ctypes.data),
                                             nbytes.value, offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
     for a, off in zip(arrs, offs):
-        host_np[int(off):int(off) + a.size] = a.reshape(-1)
+        if isinstance(a, Image.Image):
+            if not _pilmem.copy_to(a, host_np.ctypes.data + int(off)):
+                flat = np.asarray(a, dtype=np.uint8).reshape(-1)
+                host_np[int(off):int(off) + flat.size] = flat
+        else:
+            host_np[int(off):int(off) + a.size] = a.reshape(-1)
     host = torch.from_numpy(host_np)
     if pin and torch.cuda.is_available():
         host = host.pin_memory()
@@ -280,6 +300,18 @@ class ObjectImages(dict):
         self._touch()
         super().clear()
 
+    def setdefault(self, *a):
+        self._touch()
+        return super().setdefault(*a)
+
+    def popitem(self):
+        self._touch()
+        return super().popitem()
+
+    def __ior__(self, other):
+        self._touch()
+        return super().__ior__(other)
+
 
 def _i32p(a: np.ndarray):
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
@@ -365,8 +397,9 @@ def _make_job(size, bg_dev_ptr, bg_rgba, placement_arr, n_place, out_ptr) -> Job
     return j
 
 
-def _build_jobs(atlas: "Atlas", canvases, placement_rows):
-    """-> (ctypes Job array with null outputs, [(W, H)...], objects to keep alive while it is used)."""
+def _build_jobs(atlas: "Atlas", canvases, placement_rows, atlas_of: Optional[Sequence[int]] = None):
+    """-> (ctypes Job array with null outputs, [(W, H)...], objects to keep alive while it is used).
+    atlas_of[i]: index (into the call's atlas array) of the atlas canvas i's placements refer to."""
     torch = _torch()
     n = len(canvases)
     jobs = (Job * max(n, 1))()
@@ -384,7 +417,7 @@ def _build_jobs(atlas: "Atlas", canvases, placement_rows):
             H, W = int(cv.shape[0]), int(cv.shape[1])
             bg_ptr, rgba = cv.data_ptr(), (0, 0, 0, 0)
             keep.append(cv)
-        parr = _fill_placements(rows)
+        parr = _fill_placements(rows, atlas_of[i] if atlas_of is not None else 0)
         jobs[i] = _make_job((W, H), bg_ptr, rgba, parr, len(rows), None)
         keep.append(parr)
         sizes.append((W, H))
@@ -401,23 +434,32 @@ class CompositeBatch:
     canvases[i] is a SolidCanvas or a contiguous torch uint8 (H, W, 4) tensor on the atlas'
     device; placement_rows[i] = [(object_id, x1, y1, x2, y2), ...] already coerced."""
 
-    def __init__(self, atlas: Atlas, canvases: Sequence[Union[SolidCanvas, Any]],
-                 placement_rows: Sequence[Sequence[Tuple[int, int, int, int, int]]], filter: int = LANCZOS):
+    def __init__(self, atlas: Union[Atlas, Sequence[Atlas]], canvases: Sequence[Union[SolidCanvas, Any]],
+                 placement_rows: Sequence[Sequence[Tuple[int, int, int, int, int]]], filter: int = LANCZOS,
+                 atlas_of: Optional[Sequence[int]] = None):
+        """atlas: one Atlas, or several (variants of different bundles in one launch) with
+        atlas_of[i] = which of them canvas i's object ids refer to."""
         if filter not in _FILTERS:
             raise ValueError(f"unknown filter {filter}")
         torch = _torch()
-        self.atlas = atlas
-        self.ctx = atlas.ctx
+        atlases = [atlas] if isinstance(atlas, Atlas) else list(atlas)
+        if not atlases or any(a.ctx is not atlases[0].ctx for a in atlases):
+            raise ValueError("the atlases of a batch must live in one context")
+        self.atlas = atlases[0]
+        self.atlases = atlases
+        self.ctx = atlases[0].ctx
         self.filter = filter
         self.n = len(canvases)
-        if len(placement_rows) != self.n:
-            raise ValueError("one placement list per canvas")
-        jobs, self.sizes, keep = _build_jobs(atlas, canvases, placement_rows)
-        self._keep: List[Any] = [atlas] + keep
-        atl = (_P * 1)(atlas.handle)
+        if len(placement_rows) != self.n or (atlas_of is not None and len(atlas_of) != self.n):
+            raise ValueError("one placement list (and atlas index) per canvas")
+        if atlas_of is not None and any(not 0 <= int(k) < len(atlases) for k in atlas_of):
+            raise ValueError("atlas index out of range")
+        jobs, self.sizes, keep = _build_jobs(atlases[0], canvases, placement_rows, atlas_of)
+        self._keep: List[Any] = atlases + keep
+        atl = (_P * len(atlases))(*[a.handle for a in atlases])
         h = _P()
         with torch.cuda.device(self.ctx.torch_device):
-            _native.check(_native.lib().mic_plan_create(self.ctx.handle, 1, atl, self.n, jobs, filter,
+            _native.check(_native.lib().mic_plan_create(self.ctx.handle, len(atlases), atl, self.n, jobs, filter,
                                                         ctypes.byref(h)))
         self.handle = h
         self._outs = (_P * max(self.n, 1))()
@@ -504,10 +546,14 @@ def composite(background_img: Image.Image, object_images: Mapping[int, Image.Ima
     rows = coerce_placements(object_images, placements)
     if not rows:
         return background_img.copy()  # compositor.py:11 with an empty loop
-    bg = _image_to_array(background_img)
+    if background_img.mode != "RGBA":
+        raise ValueError("image has wrong mode")  # what Pillow's core.alpha_composite raises
     atlas = _as_atlas(object_images)
-    bg_dev = _upload(bg, atlas.ctx)
-    out = composite_device(atlas, [bg_dev], [rows], filter=filter)[0]
+    # The pipeline's backgrounds are fill_solid() canvases re-opened from canvas.png
+    # (macro_placement_test.py:1510): one colour.  Then nothing is uploaded, the kernel synthesises it.
+    solid = _pilmem.solid_colour(background_img)
+    canvas = SolidCanvas(background_img.size, solid) if solid is not None else _upload(background_img, atlas.ctx)
+    out = composite_device(atlas, [canvas], [rows], filter=filter)[0]
     return _to_pil(out)
 
 
@@ -584,7 +630,10 @@ def render(layout_json: Any, objects: Mapping[int, Any], canvas: Any, *, filter:
     if isinstance(canvas, Image.Image):
         if not rows and not as_tensor:
             return canvas.copy()
-        canvas = _upload(_image_to_array(canvas), atlas.ctx)
+        if canvas.mode != "RGBA":
+            raise ValueError("image has wrong mode")
+        solid = _pilmem.solid_colour(canvas)
+        canvas = SolidCanvas(canvas.size, solid) if solid is not None else _upload(canvas, atlas.ctx)
     out = composite_device(atlas, [canvas], [rows], filter=filter)[0]
     return out if as_tensor else _to_pil(out)
 

@@ -20,6 +20,20 @@
  *     enqueued asynchronously on it; outputs are complete once the stream has drained.
  *     A context must be driven from one stream at a time.
  *   - there is NO CPU fallback: without a usable HIP device mic_create fails.
+ *
+ * Threads.  Every entry point that takes a context, or a plan / an atlas of it, may be called from
+ * any thread at any time: the context carries a mutex and each call holds it from entry to return
+ * (the staging ring, the scratch arena, the table caches and the current stream are shared state),
+ * so concurrent calls on one context are serialised, calls on different contexts run in parallel.
+ * That matches the Pillow calls this library replaces, which are thread-safe (the reference's
+ * Streamlit app runs every session on its own thread).  Work is still ENQUEUED asynchronously:
+ * two threads that pass different streams make the context switch streams, which synchronises the
+ * old one (correct, slow); pass the same stream, or give each thread a context of its own.
+ * mic_destroy, mic_atlas_destroy and mic_plan_destroy must not race with calls that use the
+ * object being destroyed.  Lifetimes: atlases must outlive the plans made from them being RUN, and
+ * a context must outlive mic_plan_run / mic_composite_batch calls on it; the destroy calls
+ * themselves may come in any order (plans and atlases keep what they need to free their memory,
+ * and a plan keeps the tables it points into alive).
  */
 #ifndef MIC_H
 #define MIC_H
