@@ -200,10 +200,14 @@ __device__ __forceinline__ void edge_page(const Job &job, const Layer *jl, int64
 #ifndef MIC_HOT_WAVES
 #define MIC_HOT_WAVES 7
 #endif
-template <bool ALIGNED, bool SOLID>
+// ONE: the launch holds a single job, handed over BY VALUE in the kernel arguments (scalar loads from the
+// kernarg segment) instead of through the device job table: a wave's first memory round trip -- of the three
+// dependent ones it makes: job, layer records, cutout pixels -- disappears, and so does the table upload.
+// That is the reference's own call shape: one composite() per call (compositor.py:6-22).
+template <bool ALIGNED, bool SOLID, bool ONE>
 __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6 : 4)) void composite_kernel(
-    const Job *__restrict__ jobs, const Layer *__restrict__ layers) {
-    const Job job = jobs[blockIdx.y];
+    const Job *__restrict__ jobs, const Layer *__restrict__ layers, const Job one) {
+    const Job job = ONE ? one : jobs[blockIdx.y];
     if ((int)blockIdx.x >= job.n_pages) return;
     const int lane = threadIdx.x;
     const int W = job.W;
@@ -442,25 +446,39 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
 }
 
 // Jobs arrive sorted by class: [0, n0) aligned+solid, [n0, n1) unaligned+solid, [n1, n2) aligned with
-// a background image / translucent colour, [n2, n_jobs) neither.
+// a background image / translucent colour, [n2, n_jobs) neither.  single != nullptr: the launch's only job,
+// passed in the kernel arguments (jobs_dev is not read).
 hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_jobs, const int class_end[3],
-                            int pitch, hipStream_t stream) {
+                            int pitch, const Job *single, hipStream_t stream) {
     if (n_jobs <= 0 || pitch <= 0) return hipSuccess;
     // grid.x (= pitch) is a multiple of 8 so that (linear workgroup id) mod 8 == (page index) mod 8
     // for every job of the launch: the XCD <-> page residue pairing survives the 2-D grid.
     const int b[5] = {0, class_end[0], class_end[1], class_end[2], n_jobs};
+    if (single && n_jobs == 1) {
+        const dim3 grid((unsigned)pitch, 1u);
+        if (b[1] > b[0])
+            hipLaunchKernelGGL((composite_kernel<true, true, true>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single);
+        else if (b[2] > b[1])
+            hipLaunchKernelGGL((composite_kernel<false, true, true>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single);
+        else if (b[3] > b[2])
+            hipLaunchKernelGGL((composite_kernel<true, false, true>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single);
+        else
+            hipLaunchKernelGGL((composite_kernel<false, false, true>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single);
+        return hipGetLastError();
+    }
+    const Job none{};
     if (b[1] > b[0])
-        hipLaunchKernelGGL((composite_kernel<true, true>), dim3((unsigned)pitch, (unsigned)(b[1] - b[0])), dim3(64),
-                           0, stream, jobs_dev + b[0], layers_dev);
+        hipLaunchKernelGGL((composite_kernel<true, true, false>), dim3((unsigned)pitch, (unsigned)(b[1] - b[0])), dim3(64),
+                           0, stream, jobs_dev + b[0], layers_dev, none);
     if (b[2] > b[1])
-        hipLaunchKernelGGL((composite_kernel<false, true>), dim3((unsigned)pitch, (unsigned)(b[2] - b[1])), dim3(64),
-                           0, stream, jobs_dev + b[1], layers_dev);
+        hipLaunchKernelGGL((composite_kernel<false, true, false>), dim3((unsigned)pitch, (unsigned)(b[2] - b[1])), dim3(64),
+                           0, stream, jobs_dev + b[1], layers_dev, none);
     if (b[3] > b[2])
-        hipLaunchKernelGGL((composite_kernel<true, false>), dim3((unsigned)pitch, (unsigned)(b[3] - b[2])), dim3(64),
-                           0, stream, jobs_dev + b[2], layers_dev);
+        hipLaunchKernelGGL((composite_kernel<true, false, false>), dim3((unsigned)pitch, (unsigned)(b[3] - b[2])), dim3(64),
+                           0, stream, jobs_dev + b[2], layers_dev, none);
     if (b[4] > b[3])
-        hipLaunchKernelGGL((composite_kernel<false, false>), dim3((unsigned)pitch, (unsigned)(b[4] - b[3])), dim3(64),
-                           0, stream, jobs_dev + b[3], layers_dev);
+        hipLaunchKernelGGL((composite_kernel<false, false, false>), dim3((unsigned)pitch, (unsigned)(b[4] - b[3])), dim3(64),
+                           0, stream, jobs_dev + b[3], layers_dev, none);
     return hipGetLastError();
 }
 

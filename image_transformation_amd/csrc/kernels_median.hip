@@ -41,11 +41,16 @@ constexpr unsigned kMaxBlocks = 512;
 // deep instead of 64.
 constexpr int kCopies = 8;
 
-// scratch layout (uint32): [set][channel][256], set 0 = alpha > 0, set 1 = alpha == 0;
-// then counts[2] at kCountOff and the retirement ticket at kTicketOff.  All zero between calls.
+// scratch layout (uint32): kGlobalCopies x { [set][channel][256], counts[2] } (set 0 = alpha > 0, set 1 =
+// alpha == 0), then the retirement ticket.  All zero between calls.  Block b flushes into copy b % 8 -- the
+// XCD it runs on, as workgroups are dealt round-robin -- so that a bin's same-address atomics (they execute
+// one after another at the memory side, ~12 ns each) are spread over eight addresses: a 4K image's 506
+// blocks put 63 adds on an address instead of 506.  The last block sums the copies.
 constexpr int kSetWords = 3 * 256;
 constexpr int kCountOff = 2 * kSetWords;
-constexpr int kTicketOff = kCountOff + 2;
+constexpr int kCopyWords = kCountOff + 16;  // counts[2] + padding to a 64-byte multiple
+constexpr int kGlobalCopies = 8;
+constexpr int kTicketOff = kGlobalCopies * kCopyWords;
 static_assert(kTicketOff < (int)kMedianScratchWords, "median scratch too small");
 static_assert(kHistWaves == 16, "median_select maps 3 channels x 256 bins onto 1024 threads");
 
@@ -110,10 +115,15 @@ __device__ void median_select(const uint32_t *hist, uint32_t *out_rgba, uint32_t
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int c = t >> 8, bin = t & 255;
     const bool act = c < 3;
-    const uint32_t n0 = agent_load(hist + kCountOff);
-    const uint32_t n1 = agent_load(hist + kCountOff + 1);
-    const uint32_t v0 = act ? agent_load(hist + (0 * 3 + c) * 256 + bin) : 0u;
-    const uint32_t v1 = act ? agent_load(hist + (1 * 3 + c) * 256 + bin) : 0u;
+    uint32_t n0 = 0, n1 = 0, v0 = 0, v1 = 0;
+#pragma unroll
+    for (int g = 0; g < kGlobalCopies; ++g) {  // 32 loads issued together: one round trip
+        const uint32_t *h = hist + g * kCopyWords;
+        n0 += agent_load(h + kCountOff);
+        n1 += agent_load(h + kCountOff + 1);
+        v0 += act ? agent_load(h + (0 * 3 + c) * 256 + bin) : 0u;
+        v1 += act ? agent_load(h + (1 * 3 + c) * 256 + bin) : 0u;
+    }
     const uint32_t n = n0 != 0 ? n0 : n1;
     if (n == 0) {  // empty image (block-uniform)
         if (t == 0) out_rgba[0] = 0xff000000u;
@@ -152,21 +162,32 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const uint32_t 
     __shared__ uint32_t res[3][2];
     __shared__ uint32_t is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t n_opaque = 0, n_clear = 0;
+    const size_t stride = (size_t)gridDim.x * kHistWaves * kTripPx;
+    size_t wbase = ((size_t)blockIdx.x * kHistWaves + wave) * kTripPx;
+    // the first trip's loads are issued before the LDS histogram is cleared: the clear (and the barrier
+    // behind it) then runs in the shadow of the first memory round trip instead of in front of it
+    u32x4 ld[kChunks];
+    const bool first_whole = wbase + kTripPx <= n_px;  // wave-uniform
+    if (first_whole) {
+#pragma unroll
+        for (int u = 0; u < kChunks; ++u)
+            __builtin_memcpy(&ld[u], px + wbase + (size_t)u * 256 + (size_t)lane * 4, 16);
+    }
     for (int i = threadIdx.x; i < 2 * kSetWords * kCopies; i += blockDim.x) lh[i] = 0;
     if (threadIdx.x < 2) lcount[threadIdx.x] = 0;
     __syncthreads();
 
-    uint32_t n_opaque = 0, n_clear = 0;
-    const size_t stride = (size_t)gridDim.x * kHistWaves * kTripPx;
-    size_t wbase = ((size_t)blockIdx.x * kHistWaves + wave) * kTripPx;
-    for (; wbase + kTripPx <= n_px; wbase += stride) {  // whole trips: wave-uniform, no guards
-        u32x4 ld[kChunks];
-#pragma unroll
-        for (int u = 0; u < kChunks; ++u)
-            __builtin_memcpy(&ld[u], px + wbase + (size_t)u * 256 + (size_t)lane * 4, 16);
+    while (wbase + kTripPx <= n_px) {  // whole trips: wave-uniform, no guards
 #pragma unroll
         for (int u = 0; u < kChunks; ++u) {
             hist_chunk<true>(ld[u][0], ld[u][1], ld[u][2], ld[u][3], true, true, true, true, lh, lane, n_opaque, n_clear);
+        }
+        wbase += stride;
+        if (wbase + kTripPx <= n_px) {
+#pragma unroll
+            for (int u = 0; u < kChunks; ++u)
+                __builtin_memcpy(&ld[u], px + wbase + (size_t)u * 256 + (size_t)lane * 4, 16);
         }
     }
     if (wbase < n_px) {  // the image's ragged last trip: exactly one wave of the grid gets here
@@ -195,24 +216,28 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const uint32_t 
     }
     __syncthreads();
 
+    uint32_t *hist_copy = hist + (blockIdx.x & (kGlobalCopies - 1)) * kCopyWords;
     for (int i = threadIdx.x; i < 2 * kSetWords; i += blockDim.x) {
         uint32_t s = 0;
 #pragma unroll
         for (int k = 0; k < kCopies; ++k) s += lh[i * kCopies + ((k + threadIdx.x) & (kCopies - 1))];
-        if (s) atomicAdd(&hist[i], s);
+        if (s) atomicAdd(&hist_copy[i], s);
     }
-    if (threadIdx.x < 2 && lcount[threadIdx.x]) atomicAdd(&hist[kCountOff + threadIdx.x], lcount[threadIdx.x]);
+    if (threadIdx.x < 2 && lcount[threadIdx.x]) atomicAdd(&hist_copy[kCountOff + threadIdx.x], lcount[threadIdx.x]);
 
-    // Retirement ticket.  The barrier orders every thread's histogram atomics before thread 0's
-    // agent-scope release on the ticket (release is cumulative), so the block drawing the last
-    // ticket -- after its acquire -- sees every block's contribution.  One release per block, not a
-    // fence per wave: an agent-scope fence is an L2 write-back on gfx950.
+    // Retirement ticket, without fences.  Everything a block publishes is an agent-scope ATOMIC (performed at the
+    // memory side: there are no plain stores whose dirty L2 lines a release would have to write back), and
+    // everything the last block reads back is read with agent-scope (sc1) loads or is the value its own ticket
+    // add returned -- the hand-off form MI355X_MICROARCH.md lists as valid without a release/acquire pair, given
+    // that (1) every wave waits for its own atomics to be acknowledged (s_waitcnt vmcnt(0)) and (2) the ticket
+    // add comes behind a workgroup barrier that all those waves have passed.  The release + acquire fences this
+    // replaces (an L2 write-back and an L1 invalidate, ~1.7 us each) were a third of a small image's time.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t ticket =
-            __hip_atomic_fetch_add(hist + kTicketOff, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(hist + kTicketOff, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         is_last = ticket == gridDim.x - 1 ? 1u : 0u;
-        if (is_last) __atomic_thread_fence(__ATOMIC_ACQUIRE);
     }
     __syncthreads();
     if (!is_last) return;
@@ -226,6 +251,8 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const uint32_t 
 // hist_dev must be zero on entry (mic_create clears it once; the kernel restores that state).
 hipError_t launch_median(const void *rgba, size_t n_px, uint32_t *hist_dev, uint32_t *out_rgba_dev,
                          hipStream_t stream) {
+    // one trip (4 KiB) per wave before a block takes a second one: a 4K image then runs on 506 blocks (every
+    // CU, two deep) instead of 127 (half the CUs idle), a 492 x 492 bundle background on 15 instead of 4
     const size_t per_block = kTripPx * kHistWaves;  // pixels per block per trip
     size_t blocks = (n_px + per_block - 1) / per_block;
     if (blocks > kMaxBlocks) blocks = kMaxBlocks;

@@ -940,8 +940,11 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     }
     if (int rc = adopt_stream(ctx, stream)) return rc;
     // ---- persistent plan onto a set of outputs it has seen: no table work, no upload ----
+    // A single job travels in the kernel arguments (launch_composite): no device job table, no upload, no
+    // table cache -- a persistent single-canvas plan's run is the launch alone.
+    const bool one = n_jobs == 1;
     mic_plan::JobTable *slot_tab = nullptr;
-    if (P->persistent) {
+    if (P->persistent && !one) {
         ++P->run_counter;
         std::vector<uint64_t> key((size_t)n_jobs);
         for (int ji = 0; ji < n_jobs; ++ji)
@@ -1025,6 +1028,9 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         // everything into the staging slot's device buffer
         const size_t upload = P->persistent ? sizeof(Job) * P->ordered.size() : P->total;
         Slot *slot = nullptr;
+        if (P->persistent && one) {
+            dp = static_cast<char *>(P->tables_dev);
+        } else {
         if (int rc = acquire_slot(ctx, upload, &slot)) return rc;
         char *hp = static_cast<char *>(slot->host);
         memcpy(hp, P->ordered.data(), sizeof(Job) * P->ordered.size());
@@ -1043,13 +1049,14 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         HIP_TRY(hipMemcpyAsync(upload_dst, slot->host, upload, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipEventRecord(slot->ev, stream));
         slot->pending = true;
+        }
         if (slot_tab) {
             slot_tab->outs = std::move(key);
             memcpy(slot_tab->class_end, class_end, sizeof class_end);
             slot_tab->pitch = pitch;
         }
     }
-    const Job *jobs_dev = P->persistent ? slot_tab->dev : reinterpret_cast<const Job *>(dp);
+    const Job *jobs_dev = one ? nullptr : (P->persistent ? slot_tab->dev : reinterpret_cast<const Job *>(dp));
 
     const bool prof = ctx->profiling && ctx->prof_calls < ctx->prof_max && (ctx->prof_seen++ % ctx->prof_every) == 0;
     hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
@@ -1062,7 +1069,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
                               P->pt.max_v_out_w, P->pt.max_v_out_h, stream));
     if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
     HIP_TRY(launch_composite(jobs_dev, reinterpret_cast<const Layer *>(dp + P->off_layers), n_jobs, class_end, pitch,
-                             stream));
+                             one ? &P->ordered[0] : nullptr, stream));
     if (prof) {
         HIP_TRY(hipEventRecord(pe[2], stream));
         ++ctx->prof_calls;

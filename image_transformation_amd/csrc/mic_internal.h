@@ -112,7 +112,7 @@ constexpr int kRsUnitsPerEntry = 32;
 // c = 0 (aligned + solid opaque background), 1 (unaligned + solid), 2 (aligned + other background);
 // the rest is class 3.  pitch = max pages per job rounded up to 8.
 hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_jobs, const int class_end[3],
-                            int pitch, hipStream_t stream);
+                            int pitch, const Job *single, hipStream_t stream);
 hipError_t launch_resample_h(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_rows,
                              hipStream_t stream);
 hipError_t launch_resample_v(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_out_h,
@@ -143,9 +143,10 @@ struct alignas(16) OutlineRect {
 static_assert(sizeof(OutlineRect) == 48, "OutlineRect layout");
 hipError_t launch_rect_outlines(void *out, int W, int H, const OutlineRect *rects_dev, int n, int width,
                                 hipStream_t stream);
-// hist: uint32 [2][3][256] + counts[2] + ticket; must be zero on entry, the kernel leaves it zeroed.
+// hist: 8 copies of { uint32 [2][3][256] + counts[2] (+ padding) } + ticket; must be zero on entry, the kernel
+// leaves it zeroed.
 hipError_t launch_median(const void *rgba, size_t n_px, uint32_t *hist_dev, uint32_t *out_rgba_dev,
                          hipStream_t stream);
-constexpr size_t kMedianScratchWords = 2 * 3 * 256 + 8;
+constexpr size_t kMedianScratchWords = 8 * (2 * 3 * 256 + 16) + 8;
 
 }  // namespace mic
