@@ -39,6 +39,11 @@ class Job(ctypes.Structure):
                 ("out_dev", ctypes.c_void_p)]
 
 
+class LabelStrip(ctypes.Structure):
+    _fields_ = [("cell", ctypes.c_int32), ("x", ctypes.c_int32), ("y", ctypes.c_int32), ("w", ctypes.c_int32),
+                ("h", ctypes.c_int32), ("coverage_host", ctypes.c_void_p)]
+
+
 class Stats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in
                 ("canvas_pixels", "layer_pixels", "source_pixels", "resampled_layers", "identity_layers",
@@ -91,6 +96,9 @@ SYMBOLS = {
     "mic_render": (ctypes.c_int, [_P, _P, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, _P,
                                   ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, _P, _P, _I32P]),
     "mic_thumbnail_size": (ctypes.c_int, [ctypes.c_int32] * 4 + [_I32P, _I32P]),
+    "mic_contact_sheet_size": (ctypes.c_int, [ctypes.c_int32] * 5 + [_I32P, _I32P]),
+    "mic_contact_sheet": (ctypes.c_int, [_P, _P, ctypes.c_int32, _I32P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, _P, _P]),
     "mic_last_stats": (ctypes.c_int, [_P, ctypes.POINTER(Stats)]),
     "mic_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
     "mic_profile_begin_sampled": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),

@@ -263,15 +263,45 @@ class Atlas(Mapping):
             self.handle = None
 
 
+class _AtlasCache:
+    """Device atlases of bundles loaded from files, by the files' (path, mtime, size) keys: the reference
+    decodes a bundle's cutouts for the contact sheet and again in every iteration's load_object_images
+    (macro_placement_test.py:1414, 1493, 1679) -- here all of those share ONE upload for as long as the
+    files do not change.  A handful of bundles is kept (least recently used goes first)."""
+    _items: "Dict[Any, Atlas]" = {}
+    _lock = threading.Lock()
+    LIMIT = 4
+
+    @classmethod
+    def get(cls, key, device, build):
+        k = (key, device)
+        with cls._lock:
+            a = cls._items.pop(k, None)
+            if a is not None:
+                cls._items[k] = a  # most recently used last
+                return a
+        a = build()
+        with cls._lock:
+            cls._items[k] = a
+            while len(cls._items) > cls.LIMIT:
+                cls._items.pop(next(iter(cls._items)))
+        return a
+
+
 class ObjectImages(dict):
     """dict {id: RGBA Image} as load_object_images returns it, plus a lazily uploaded Atlas that
     is dropped whenever the dict is modified."""
 
     _atlas: Optional[Atlas] = None
+    _source_key = None  # set by load_object_images: identifies the files the (unmodified) dict was decoded from
 
     def atlas(self, device: Optional[int] = None) -> Atlas:
         if self._atlas is None or (device is not None and self._atlas.ctx.device != device):
-            self._atlas = Atlas(self, device)
+            if self._source_key is not None:
+                dev = _native.context(device).device
+                self._atlas = _AtlasCache.get(self._source_key, dev, lambda: Atlas(self, device))
+            else:
+                self._atlas = Atlas(self, device)
         return self._atlas
 
     _native_table = None  # (ids, widths, heights) arrays cached by flex.native_boxes
@@ -279,6 +309,7 @@ class ObjectImages(dict):
     def _touch(self):
         self._atlas = None
         self._native_table = None
+        self._source_key = None  # no longer what the files hold
 
     def __setitem__(self, k, v):
         self._touch()
@@ -332,8 +363,13 @@ def load_object_images(results_json_path: str) -> Dict[int, Image.Image]:
         items = json.load(f)
     base = os.path.dirname(results_json_path)
     out = ObjectImages()
+    keys = []
     for it in items:
-        out[int(it["object_id"])] = open_rgba(os.path.join(base, it["filename"]))
+        path = os.path.join(base, it["filename"])
+        out[int(it["object_id"])] = open_rgba(path)
+        st = os.stat(path)
+        keys.append((int(it["object_id"]), os.path.abspath(path), st.st_mtime_ns, st.st_size))
+    out._source_key = tuple(keys)  # (after the inserts above, which reset it)
     return out
 
 

@@ -19,7 +19,7 @@ import numpy as np
 from PIL import Image, ImageDraw, ImageFont
 
 from . import _native
-from .compositor import open_rgba, Atlas, SolidCanvas, _to_pil, LANCZOS
+from .compositor import open_rgba, load_object_images, Atlas, SolidCanvas, _device_guard, _to_pil, LANCZOS
 
 _P = ctypes.c_void_p
 _MARGIN = 32
@@ -84,51 +84,63 @@ def build_labeled_contact_sheet(objects_dir: str, results_json_path: str,
                                 thumb_size: Tuple[int, int] = (256, 256), cols: int = 4,
                                 label_height: int = 72, font_size: int = 24,
                                 as_tensor: bool = False):
-    """Drop-in for _build_labeled_contact_sheet (objects_dir is unused there too: :191)."""
+    """Drop-in for _build_labeled_contact_sheet (objects_dir is unused there too: :191).
+
+    The cutouts come through load_object_images (per-process decode cache) and its resident atlas -- the same
+    upload every later composite of the bundle uses; thumbnails, tiling and the label blend are ONE
+    mic_contact_sheet call (a single composite job inside libmic)."""
     with open(results_json_path, "r", encoding="utf-8") as f:
         items = json.load(f)
     items = sorted(items, key=lambda it: int(it["object_id"]))
     font = _resolve_font(font_size)
+    tw_req, th_req, label_height, cols = int(thumb_size[0]), int(thumb_size[1]), int(label_height), int(cols)
+    cell_w, cell_h = tw_req, th_req + label_height
+    if not items:
+        return SolidCanvas((cell_w, cell_h), (255, 255, 255, 255)).to_image()
 
-    cutouts: List[Image.Image] = []
-    labels: List[str] = []
-    for it in items:
-        cutouts.append(open_rgba(Path(results_json_path).parent / it["filename"]))
-        labels.append(str(it.get("label", f"id_{it['object_id']}")))
+    objects = load_object_images(results_json_path)  # {id: image}; files missing -> FileNotFoundError like the reference
+    atlas = objects.atlas()
+    ids = [int(it["object_id"]) for it in items]
+    labels = [str(it.get("label", f"id_{it['object_id']}")) for it in items]
+    if len(set(ids)) != len(ids):
+        # duplicate ids: the reference draws each file it lists; a dict keeps one per id -> private atlas by position
+        cutouts = [open_rgba(Path(results_json_path).parent / it["filename"]) for it in items]
+        atlas = Atlas({i: im for i, im in enumerate(cutouts)})
+        ids = list(range(len(cutouts)))
 
-    cell_w, cell_h = int(thumb_size[0]), int(thumb_size[1]) + int(label_height)
-    if not cutouts:
-        sheet = SolidCanvas((cell_w, cell_h), (255, 255, 255, 255))
-        return sheet.to_image()
-
-    rows_n = (len(cutouts) + cols - 1) // cols
-    sheet = SolidCanvas((cols * cell_w, rows_n * cell_h), (255, 255, 255, 255))
     probe = ImageDraw.Draw(Image.new("RGBA", (1, 1)))
-
-    # layers: cutouts keep indices 0..n-1, label strips n..2n-1, all in one atlas
-    pixels = {i: im for i, im in enumerate(cutouts)}
-    rows: List[Tuple[int, int, int, int, int]] = []
-    n = len(cutouts)
-    for idx, (im, label) in enumerate(zip(cutouts, labels)):
+    strips = (_native.LabelStrip * max(len(ids), 1))()
+    keep: List[np.ndarray] = []
+    n_strips = 0
+    for idx, (oid, label) in enumerate(zip(ids, labels)):
         r, c = divmod(idx, cols)
         x_cell, y_cell = c * cell_w, r * cell_h
-        tw_, th_ = thumbnail_size(im.size, (int(thumb_size[0]), int(thumb_size[1])))
-        x = x_cell + (cell_w - tw_) // 2
-        y = y_cell + (int(thumb_size[1]) - th_) // 2
-        rows.append((idx, x, y, x + tw_, y + th_))
         tw, th_text = _measure_label(probe, label, font)
         tx = x_cell + (cell_w - tw) // 2
-        ty = y_cell + int(thumb_size[1]) + max(0, (label_height - th_text) // 2)
+        ty = y_cell + th_req + max(0, (label_height - th_text) // 2)
         strip = _label_strip(label, font, tx, ty)
-        if strip is not None:
-            arr, sx, sy = strip
-            pixels[n + idx] = arr
-            rows.append((n + idx, sx, sy, sx + arr.shape[1], sy + arr.shape[0]))
+        if strip is None:
+            continue
+        arr, sx, sy = strip
+        mask = np.ascontiguousarray(arr[:, :, 3])
+        keep.append(mask)
+        st = strips[n_strips]
+        st.cell, st.x, st.y, st.w, st.h = idx, int(sx), int(sy), int(mask.shape[1]), int(mask.shape[0])
+        st.coverage_host = mask.ctypes.data
+        n_strips += 1
 
-    from .compositor import composite_device
-
-    atlas = Atlas(pixels)
-    out = composite_device(atlas, [sheet], [rows], filter=LANCZOS)[0]
+    lib = _native.lib()
+    W, H = ctypes.c_int32(), ctypes.c_int32()
+    _native.check(lib.mic_contact_sheet_size(len(ids), tw_req, th_req, cols, label_height, ctypes.byref(W), ctypes.byref(H)))
+    import torch
+    ctx = atlas.ctx
+    out = torch.empty((H.value, W.value, 4), dtype=torch.uint8, device=ctx.torch_device)
+    ids_a = np.asarray(ids, np.int32)
+    with _device_guard(ctx):
+        _native.check(lib.mic_contact_sheet(ctx.handle, atlas.handle, len(ids), ids_a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                            tw_req, th_req, cols, label_height, n_strips, ctypes.cast(strips, ctypes.c_void_p),
+                                            _P(out.data_ptr()), _P(ctx.stream_ptr())))
+    del keep
     return out if as_tensor else _to_pil(out)
 
 

@@ -45,7 +45,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *mic_last_error(void) { return g_err; }
-extern "C" int mic_version(void) { return (1 << 16) | 3; }  // 1.3: + mic_render, mic_draw_rect_outlines, mic_profile_begin_sampled
+extern "C" int mic_version(void) { return (1 << 16) | 4; }  // 1.4: + mic_contact_sheet(_size); thread-safe contexts
 
 // ------------------------------------------------------------------------------------ blob layout
 namespace {
@@ -1128,6 +1128,77 @@ extern "C" int mic_render(mic_ctx *ctx, mic_atlas *atlas, const char *layout_jso
     job.out_dev = out_dev;
     mic_atlas *atl[1] = {atlas};
     return mic_composite_batch(ctx, 1, atl, 1, &job, filter, stream_v);
+}
+
+extern "C" int mic_contact_sheet_size(int32_t n, int32_t thumb_w, int32_t thumb_h, int32_t cols, int32_t label_h,
+                                      int32_t *sheet_w, int32_t *sheet_h) {
+    if (!sheet_w || !sheet_h || n < 0 || thumb_w <= 0 || thumb_h <= 0 || cols <= 0 || label_h < 0)
+        return fail(MIC_ERR_INVALID, "mic_contact_sheet_size: bad arguments");
+    const int64_t cell_w = thumb_w, cell_h = (int64_t)thumb_h + label_h;
+    // macro_placement_test.py:198-207: an empty list gives one blank cell
+    const int64_t w = n == 0 ? cell_w : (int64_t)cols * cell_w;
+    const int64_t h = n == 0 ? cell_h : (int64_t)((n + cols - 1) / cols) * cell_h;
+    if (w > kMaxDim || h > kMaxDim) return fail(MIC_ERR_INVALID, "contact sheet of %lldx%lld is too large", (long long)w, (long long)h);
+    *sheet_w = (int32_t)w;
+    *sheet_h = (int32_t)h;
+    return MIC_OK;
+}
+
+extern "C" int mic_contact_sheet(mic_ctx *ctx, mic_atlas *atlas, int32_t n, const int32_t *object_ids, int32_t thumb_w,
+                                 int32_t thumb_h, int32_t cols, int32_t label_h, int32_t n_strips,
+                                 const mic_label_strip *strips, void *out_dev, void *stream_v) {
+    CTX_ENTER(ctx);
+    int32_t W = 0, H = 0;
+    if (int rc = mic_contact_sheet_size(n, thumb_w, thumb_h, cols, label_h, &W, &H)) return rc;
+    if (!atlas || !out_dev || (n > 0 && !object_ids) || n_strips < 0 || (n_strips > 0 && !strips))
+        return fail(MIC_ERR_INVALID, "mic_contact_sheet: bad arguments");
+    if (atlas->ctx != ctx) return fail(MIC_ERR_INVALID, "mic_contact_sheet: atlas belongs to another context");
+    const int cell_w = thumb_w, cell_h = thumb_h + label_h;
+    // the labels become a throw-away atlas of black RGBA strips whose alpha is the coverage mask: blending one
+    // with the alpha-over kernel is ImageDraw.text's own mask blend on an opaque sheet, div255(dst * (255 - m) + 128)
+    std::vector<std::vector<uint8_t>> rgba((size_t)n_strips);
+    std::vector<int32_t> sid((size_t)n_strips), sw((size_t)n_strips), sh((size_t)n_strips);
+    std::vector<const uint8_t *> sp((size_t)n_strips);
+    for (int k = 0; k < n_strips; ++k) {
+        const mic_label_strip &S = strips[k];
+        if (S.w <= 0 || S.h <= 0 || !S.coverage_host || S.cell < 0 || S.cell >= n)
+            return fail(MIC_ERR_INVALID, "mic_contact_sheet: label strip %d is malformed", k);
+        if ((int64_t)S.w * S.h > kMaxLayerPx) return fail(MIC_ERR_INVALID, "mic_contact_sheet: label strip %d is too large", k);
+        rgba[(size_t)k].assign((size_t)S.w * S.h * 4, 0);
+        for (size_t i = 0; i < (size_t)S.w * S.h; ++i) rgba[(size_t)k][4 * i + 3] = S.coverage_host[i];
+        sid[(size_t)k] = k; sw[(size_t)k] = S.w; sh[(size_t)k] = S.h; sp[(size_t)k] = rgba[(size_t)k].data();
+    }
+    mic_atlas *labels = nullptr;
+    if (n_strips > 0)
+        if (int rc = mic_atlas_create(ctx, n_strips, sid.data(), sw.data(), sh.data(), sp.data(), &labels)) return rc;
+    std::vector<mic_placement> pl;
+    for (int i = 0; i < n; ++i) {
+        auto it = atlas->index.find(object_ids[i]);
+        if (it == atlas->index.end()) {
+            mic_atlas_destroy(labels);
+            return fail(MIC_ERR_INVALID, "mic_contact_sheet: object id %d is not in the atlas", object_ids[i]);
+        }
+        const BlobEntry &E = atlas->entries[(size_t)it->second];
+        int tw = 0, th = 0;
+        thumbnail_size(E.w, E.h, thumb_w, thumb_h, &tw, &th);
+        const int r = i / cols, c = i % cols;
+        // :216-217, Python floor division (tw <= thumb_w and th <= thumb_h: never negative)
+        const int x = c * cell_w + (cell_w - tw) / 2, y = r * cell_h + (thumb_h - th) / 2;
+        pl.push_back(mic_placement{0, object_ids[i], {x, y, x + tw, y + th}});
+        for (int k = 0; k < n_strips; ++k)
+            if (strips[k].cell == i)
+                pl.push_back(mic_placement{1, k, {strips[k].x, strips[k].y, strips[k].x + strips[k].w, strips[k].y + strips[k].h}});
+    }
+    mic_job job{};
+    job.width = W; job.height = H;
+    job.bg_rgba[0] = job.bg_rgba[1] = job.bg_rgba[2] = job.bg_rgba[3] = 255;  // :207 white, opaque
+    job.n_placements = (int32_t)pl.size();
+    job.placements = pl.data();
+    job.out_dev = out_dev;
+    mic_atlas *atl[2] = {atlas, labels};
+    int rc = mic_composite_batch(ctx, labels ? 2 : 1, atl, 1, &job, MIC_FILTER_LANCZOS, stream_v);
+    mic_atlas_destroy(labels);  // waits for the device: the launch has read the strips by then
+    return rc;
 }
 
 extern "C" int mic_plan_create(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,

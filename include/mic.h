@@ -172,6 +172,28 @@ int mic_draw_rect_outlines(mic_ctx *ctx, void *out_dev, int32_t width, int32_t h
                            const int32_t *boxes_xyxy, const uint8_t *colours_rgba, int32_t outline_width,
                            void *stream);
 
+/* ---- contact sheet: replaces _build_labeled_contact_sheet's pixel work ----------------------
+ * (macro_placement_test.py:162-242).  The n cutouts `object_ids` of `atlas`, in sheet order (the
+ * reference sorts the items by object_id, :173), each reduced by Image.thumbnail((thumb_w, thumb_h),
+ * LANCZOS) (:194; a cutout that already fits keeps its size) and alpha-composited centred in the top
+ * thumb_h rows of its cell (:216-218) of an opaque white sheet of cols cells per row, each cell
+ * thumb_w x (thumb_h + label_h) (:201-207); n == 0 gives one blank cell (:198-199).  Text stays on the
+ * host (FreeType): every label arrives as an 8-bit coverage mask, `coverage_host` (w x h bytes, row-major),
+ * with its position on the sheet, and is blended as ImageDraw.text(fill=(0,0,0,255)) blends it onto an
+ * opaque sheet (:240); a strip is drawn right after the thumbnail of cell `cell` (the reference's order:
+ * thumbnail, label, next cell).  out_dev: the sheet, RGBA, mic_contact_sheet_size() pixels.
+ * An object id that is not in the atlas is MIC_ERR_INVALID (the reference fails opening its file).   */
+typedef struct mic_label_strip {
+    int32_t cell;                 /* index into object_ids of the thumbnail this label follows */
+    int32_t x, y, w, h;           /* position (may overhang the sheet: clipped) and size of the mask */
+    const uint8_t *coverage_host; /* w*h bytes */
+} mic_label_strip;
+int mic_contact_sheet_size(int32_t n, int32_t thumb_w, int32_t thumb_h, int32_t cols, int32_t label_h,
+                           int32_t *sheet_w, int32_t *sheet_h);
+int mic_contact_sheet(mic_ctx *ctx, mic_atlas *atlas, int32_t n, const int32_t *object_ids, int32_t thumb_w,
+                      int32_t thumb_h, int32_t cols, int32_t label_h, int32_t n_strips,
+                      const mic_label_strip *strips, void *out_dev, void *stream);
+
 /* ---- layout: the integer half of render() -------------------------------------------------
  * Flex-DSL JSON text ({"root": {...}}) + cutout sizes + canvas size -> object ids and clamped boxes
  * in depth-first order: _measure_flex_node / _place_flex_container / _clamp_boxes_to_canvas

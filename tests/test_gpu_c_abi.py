@@ -249,3 +249,54 @@ def test_fragment_cache_eviction_keeps_plans_valid():
     assert n.value == 3 and comp.value > 0 and res.value > 0
     assert lib.mic_profile_begin_sampled(ctx, 10, 0) < 0
     assert lib.mic_plan_destroy(plan) == 0 and lib.mic_atlas_destroy(atlas) == 0 and lib.mic_destroy(ctx) == 0
+
+
+def test_raw_abi_contact_sheet(abi, golden_dir):
+    """mic_contact_sheet through the raw ABI against the sheets captured from the reference
+    (_build_labeled_contact_sheet, macro_placement_test.py:162-242): the thumbnail band of every cell bit-exact;
+    a label strip handed over as a coverage mask lands where it is put, blended as ImageDraw.text blends it
+    on the opaque sheet; unknown ids and the empty sheet follow the header's contract."""
+    import json
+    import os
+    import torch
+    from PIL import Image
+    lib, ctx, nat = abi
+    arrays = np.load(os.path.join(golden_dir, "contact_sheet.npz"))
+    for bundle in ("squarespace", "audio_book"):
+        rj = os.path.join(cases.BUNDLE_DIR, bundle, "results.json")
+        with open(rj, encoding="utf-8") as f:
+            items = sorted(json.load(f), key=lambda it: int(it["object_id"]))
+        objs = {int(it["object_id"]): np.array(Image.open(os.path.join(cases.BUNDLE_DIR, bundle, it["filename"])).convert("RGBA"))
+                for it in items}
+        atlas = _make_atlas(lib, ctx, objs)
+        ids = (ctypes.c_int32 * len(objs))(*objs.keys())
+        W, H = ctypes.c_int32(), ctypes.c_int32()
+        assert lib.mic_contact_sheet_size(len(objs), 256, 256, 4, 72, ctypes.byref(W), ctypes.byref(H)) == 0
+        want = arrays[f"{bundle}_sheet"]
+        assert (H.value, W.value) == want.shape[:2]
+        out = torch.zeros((H.value, W.value, 4), dtype=torch.uint8, device="cuda")
+        # one label: a 5 x 3 coverage mask under the second thumbnail
+        mask = np.array([[0, 64, 128, 255, 255], [255, 255, 0, 1, 254], [7, 7, 7, 7, 7]], np.uint8)
+        strip = nat.LabelStrip()
+        strip.cell, strip.x, strip.y, strip.w, strip.h = 1, 300, 270, 5, 3
+        strip.coverage_host = mask.ctypes.data
+        assert lib.mic_contact_sheet(ctx, atlas, len(objs), ids, 256, 256, 4, 72, 1, ctypes.byref(strip),
+                                     P(out.data_ptr()), _stream()) == 0, lib.mic_last_error()
+        got = out.cpu().numpy()
+        assert np.array_equal(got[:256], want[:256])  # LANCZOS thumbnails + alpha-over on white, as the reference's
+        band = np.full((72, W.value, 4), 255, np.uint8)  # the label band: white, except the strip
+        m = mask.astype(np.uint32)
+        t = 255 * (255 - m) + 128  # black ink over white, Pillow's blend: div255(dst * (255 - m) + 128)
+        band[270 - 256:273 - 256, 300:305, :3] = (((t >> 8) + t) >> 8)[:, :, None]
+        assert np.array_equal(got[256:], band)
+        # an id the atlas does not hold
+        bad = (ctypes.c_int32 * 1)(99)
+        assert lib.mic_contact_sheet(ctx, atlas, 1, bad, 256, 256, 4, 72, 0, None, P(out.data_ptr()), _stream()) < 0
+        assert b"not in the atlas" in lib.mic_last_error()
+        # the empty sheet: one blank cell
+        assert lib.mic_contact_sheet_size(0, 256, 256, 4, 72, ctypes.byref(W), ctypes.byref(H)) == 0
+        assert (W.value, H.value) == (256, 328)
+        blank = torch.zeros((328, 256, 4), dtype=torch.uint8, device="cuda")
+        assert lib.mic_contact_sheet(ctx, atlas, 0, None, 256, 256, 4, 72, 0, None, P(blank.data_ptr()), _stream()) == 0
+        assert bool((blank == 255).all())
+        assert lib.mic_atlas_destroy(atlas) == 0
