@@ -320,6 +320,21 @@ def gen_big_hashes():
     dump_json("big_hashes.json", {"meta": META, "cases": rows})
 
 
+def gen_c4_all():
+    """BASELINE.json configs[3] in full: all 64 aspect-ratio variants of the 32-object bundle through the
+    reference (place + clamp + composite), hashes only.  What the multi-rank test shards over its ranks."""
+    rows = []
+    objs, variants = synthetic.c4_workload("binary", n_variants=64)
+    imgs = {k: to_img(v) for k, v in objs.items()}
+    for v, ((W, H), layout) in enumerate(variants):
+        placed: list = []
+        ref_mp._place_flex_container(layout["root"], (0, 0), (W, H), imgs, placed, "flex_root")
+        ref_mp._clamp_boxes_to_canvas(placed, (W, H))
+        out = to_arr(ref_comp.composite(Image.new("RGBA", (W, H), synthetic.SOLID_BG), imgs, placed))
+        rows.append({"name": f"c4_variant_{v}", "canvas": [W, H], "sha16": cases.sha16(out)})
+    dump_json("c4_hashes.json", {"meta": META, "cases": rows})
+
+
 def gen_gradient():
     """background_resizing.fill_gradient / _edge_strip_median_colors (dead code in the reference today,
     SURVEY.md section 8f row 3) on the two bundles and two small synthetic backgrounds."""
@@ -394,10 +409,11 @@ def gen_overlay():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["bundles_copy", "canvas", "flex", "composite", "resize", "median", "bundles",
-                             "contact", "big", "gradient", "overlay"]
+                             "contact", "big", "c4", "gradient", "overlay"]
     steps = {"bundles_copy": copy_bundles, "canvas": gen_canvas_sizes, "flex": gen_flex,
              "composite": gen_composite, "resize": gen_resize, "median": gen_median, "bundles": gen_bundles,
-             "contact": gen_contact_sheets, "big": gen_big_hashes, "gradient": gen_gradient, "overlay": gen_overlay}
+             "contact": gen_contact_sheets, "big": gen_big_hashes, "c4": gen_c4_all, "gradient": gen_gradient,
+             "overlay": gen_overlay}
     for w in which:
         print("==", w, flush=True)
         steps[w]()
