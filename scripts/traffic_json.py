@@ -1,0 +1,41 @@
+"""Build profiles/rNN_*_traffic.json from a rocprofv3 FETCH_SIZE pass and a WRITE_SIZE pass (separate --pmc runs) and a
+kernel-trace stats CSV: per-launch means for one kernel, with the gfx950 corrections of MI355X_MICROARCH.md applied.
+usage: traffic_json.py <kernel substring> <fetch dir> <write dir> <kernel_stats.csv> <algorithmic bytes> <out.json> [note]"""
+import csv, glob, json, sys
+
+kern, fdir, wdir, stats_csv, alg, out = sys.argv[1:7]
+note = sys.argv[7] if len(sys.argv) > 7 else ""
+
+
+def mean_counter(d, name):
+    vals = []
+    for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kern in r["Kernel_Name"] and r["Counter_Name"] == name:
+                vals.append(float(r["Counter_Value"]))
+    # the first launches of a run include cold code/table fetches: take the steady tail
+    vals = vals[len(vals) // 4:] or vals
+    return sum(vals) / max(len(vals), 1), len(vals)
+
+
+fetch_kb, nf = mean_counter(fdir, "FETCH_SIZE")
+write_kb, nw = mean_counter(wdir, "WRITE_SIZE")
+trace = None
+for r in csv.DictReader(open(stats_csv)):
+    if kern in r["Name"]:
+        trace = {"calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]),
+                 "min_ns": float(r.get("MinNs", 0) or 0), "max_ns": float(r.get("MaxNs", 0) or 0)}
+rd, wr = int(fetch_kb * 1024 * 2), int(write_kb * 1024)
+rec = {"kernel": kern, "per_launch": {"FETCH_SIZE_KB": round(fetch_kb, 1), "WRITE_SIZE_KB": round(write_kb, 1),
+                                      "fabric_read_bytes": rd, "fabric_write_bytes": wr, "hbm_bytes": rd + wr,
+                                      "algorithmic_bytes": int(alg), "launches_averaged": [nf, nw]},
+       "corrections": "gfx950: FETCH_SIZE counts 128-B read requests at 64 B, so wide coalesced reads are doubled "
+                      "(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-B-per-lane streaming stores. Both sit "
+                      "on the L2's fabric side: reads served by the Infinity Cache are included, reads served by L2 are not.",
+       "kernel_trace": trace, "note": note}
+if trace:
+    t = trace["average_ns"] * 1e-9
+    rec["rates"] = {"algorithmic_GBps": round(int(alg) / t / 1e9, 1), "frac_of_8TBps": round(int(alg) / t / 8e12, 4),
+                    "measured_traffic_GBps": round((rd + wr) / t / 1e9, 1)}
+json.dump(rec, open(out, "w"), indent=1)
+print(json.dumps(rec))
