@@ -202,10 +202,19 @@ __device__ __forceinline__ uint32_t premultiply2_hi(uint32_t x, uint32_t a) {
 // recogniser, which does not look inside asm statements (an asm version read the accumulator early and
 // produced saturated garbage).  The builtin returns 16 bits, so the upper half's stale bits -- what
 // hipcc's own pattern-matched use of the instruction gets wrong, see clip8 -- are dropped explicitly.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t clip8x4(v4i v) {
-    const uint32_t lo = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(v[0], v[1], 6);
-    const uint32_t hi = (unsigned short)__builtin_amdgcn_ashr_pk_u8_i32(v[2], v[3], 6);
-    return lo | (hi << 16);
+    // (two 16-bit halves built as a vector: the compiler then gathers them with ONE v_perm_b32; widening the
+    // halves to 32 bits first costs a mask each)
+    const u16x2 p = {__builtin_amdgcn_ashr_pk_u8_i32(v[0], v[1], 6), __builtin_amdgcn_ashr_pk_u8_i32(v[2], v[3], 6)};
+    return __builtin_bit_cast(uint32_t, p);
+}
+// The same with SIGNED saturation to -128..127: with 128 << 22 taken off the bias beforehand this is
+// clip8(...) - 128, the signed-byte form the next pass' MFMA operand wants (clamp(x, 0, 255) - 128 ==
+// clamp(x - 128, -128, 127)), without the xor 0x80 per word.
+__device__ __forceinline__ uint32_t clip8x4_signed(v4i v) {
+    const u16x2 p = {__builtin_amdgcn_ashr_pk_i8_i32(v[0], v[1], 6), __builtin_amdgcn_ashr_pk_i8_i32(v[2], v[3], 6)};
+    return __builtin_bit_cast(uint32_t, p);
 }
 
 __device__ __forceinline__ v4i shr8(v4i v) { return v4i{v[0] >> 8, v[1] >> 8, v[2] >> 8, v[3] >> 8}; }
@@ -215,7 +224,7 @@ __device__ __forceinline__ v4i shr8(v4i v) { return v4i{v[0] >> 8, v[1] >> 8, v[
 // chunk's tap digits (B); fbase = where the tile's fragments start (further chunks -- windows wider than
 // 64 samples: shrinks below ~1/3 -- are read from there).  SINGLE: one chunk, the four channels' chains
 // are written side by side so that each MFMA's latency is covered by the other channels' work.
-template <bool SINGLE, class Load>
+template <bool SINGLE, bool SIGNED, class Load>
 __device__ __forceinline__ void tile4(Load load, const v4i (&f)[3], gv4ptr fbase, int n_chunks, v4i bias,
                                       uint32_t (&w)[4]) {
     if (SINGLE) {
@@ -234,8 +243,8 @@ __device__ __forceinline__ void tile4(Load load, const v4i (&f)[3], gv4ptr fbase
             y = shr8(y);
             x = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, f[2], x, 0, 0, 0);
             y = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, f[2], y, 0, 0, 0);
-            w[c0] = clip8x4(x);
-            w[c0 + 1] = clip8x4(y);
+            w[c0] = SIGNED ? clip8x4_signed(x) : clip8x4(x);
+            w[c0 + 1] = SIGNED ? clip8x4_signed(y) : clip8x4(y);
         }
     } else {
         v4i acc[4];
@@ -255,7 +264,7 @@ __device__ __forceinline__ void tile4(Load load, const v4i (&f)[3], gv4ptr fbase
             }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) w[c] = clip8x4(acc[c]);
+        for (int c = 0; c < 4; ++c) w[c] = SIGNED ? clip8x4_signed(acc[c]) : clip8x4(acc[c]);
     }
 }
 
@@ -372,7 +381,8 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
     const v4i hm_v = hmeta[xt0 + (active ? wave : 0)];  // the same for every lane: kept in scalar registers
     const int hm[3] = {__builtin_amdgcn_readfirstlane(hm_v[0]), __builtin_amdgcn_readfirstlane(hm_v[1]),
                        __builtin_amdgcn_readfirstlane(hm_v[2])};
-    const int hb = reinterpret_cast<gciptr>(J.hbias)[(xt0 + (active ? wave : 0)) * 16 + l15];
+    // (- 128 << 22: the horizontal pass clips to signed bytes, see clip8x4_signed)
+    const int hb = reinterpret_cast<gciptr>(J.hbias)[(xt0 + (active ? wave : 0)) * 16 + l15] - (128 << 22);
     const v4i hbias = {hb, hb, hb, hb};
     gv4ptr hfbase = reinterpret_cast<gv4ptr>(J.hfrag) + (size_t)hm[2] * 3 * 64 + lane;
     const v4i hf[3] = {hfbase[0], hfbase[64], hfbase[128]};
@@ -401,14 +411,17 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
     for (int b = band0; b <= band_last; ++b) {
         __syncthreads();  // every wave is done reading the previous band
         {
-            uint32_t seen = 0;  // alpha plane (wave 3): OR of (alpha ^ 0x80) bytes, zero iff every alpha is 0
-            const int k80 = (int)0x80808080u;
 #pragma unroll
             for (int k = 0; k < 2; ++k)
-                if (cl + 4 * k < n16) {
-                    *reinterpret_cast<v4i *>(lds_dst + 64 * k) = pre[k];
-                    seen |= (uint32_t)((pre[k][0] ^ k80) | (pre[k][1] ^ k80) | (pre[k][2] ^ k80) | (pre[k][3] ^ k80));
-                }
+                if (cl + 4 * k < n16) *reinterpret_cast<v4i *>(lds_dst + 64 * k) = pre[k];
+            uint32_t seen = 0;  // alpha plane (wave 3): OR of (alpha ^ 0x80) bytes, zero iff every alpha is 0
+            const int k80 = (int)0x80808080u;
+            if (wave == 3) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (cl + 4 * k < n16)
+                        seen |= (uint32_t)((pre[k][0] ^ k80) | (pre[k][1] ^ k80) | (pre[k][2] ^ k80) | (pre[k][3] ^ k80));
+            }
             if (n16 > 8) {  // strips of deep shrinks: the rest of the band, not prefetched
                 const uint64_t g = band_row(b);
                 for (int k = 2; cl + 4 * k < n16; ++k) {
@@ -437,10 +450,10 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                 // D[row = 4 lh + reg (band row)][col = l15 (x)]: 4 consecutive rows of one column
                 uint32_t w[4];
                 auto load = [&](int c, int ch) { return *reinterpret_cast<const v4i *>(a0 + c * plane_s + 64 * ch); };
-                if (hm[1] == 1) tile4<true>(load, hf, hfbase, 1, hbias, w);
-                else tile4<false>(load, hf, hfbase, hm[1], hbias, w);
+                if (hm[1] == 1) tile4<true, true>(load, hf, hfbase, 1, hbias, w);
+                else tile4<false, true>(load, hf, hfbase, hm[1], hbias, w);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m0 + 16 * slot + c * plane_r) = w[c] ^ 0x80808080u;
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m0 + 16 * slot + c * plane_r) = w[c];
             }
         }
         // ---- tiles of output rows whose last tap row is now in the ring
@@ -467,8 +480,8 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                     auto load = [&](int c, int ch) {
                         return *reinterpret_cast<const v4i *>(r0 + c * plane_r + (((base16 + 4 * ch) & rmask) << 4));
                     };
-                    if (v_nch == 1) tile4<true>(load, vf, vfbase, 1, vbias, w);
-                    else tile4<false>(load, vf, vfbase, v_nch, vbias, w);
+                    if (v_nch == 1) tile4<true, false>(load, vf, vfbase, 1, vbias, w);
+                    else tile4<false, false>(load, vf, vfbase, v_nch, vbias, w);
                     // alpha bytes all 0 or 255 <=> low 7 bits of every byte equal its top bit
                     const uint32_t top = (w[3] >> 7) & 0x01010101u;
                     const bool soft = (w[3] & 0x7F7F7F7Fu) != (top << 7) - top;
