@@ -465,31 +465,34 @@ def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_
                     [coerce_placements(c4atlas, flex.layout_to_placements(l, c4atlas, s)) for s, l in mixed]))
     del satlas, c4atlas
 
-    # ---- placements mode (direct composite() callers): Pillow-exact LANCZOS resample + overlaps
-    psize, pobjs, ppl = synthetic.placements_workload(W, H, 32, 3, "soft")
-    patlas = Atlas(pobjs)
-    pplan = CompositeBatch(patlas, [SolidCanvas(psize, synthetic.SOLID_BG)], [coerce_placements(patlas, ppl)])
-    pout = pplan.alloc_outputs()
-    for _ in range(3):
-        pplan.run(pout)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(10):
-        pplan.run(pout, check=False)
-    torch.cuda.synchronize()
-    e2 = time.perf_counter() - t0
-    c2, r2 = bracketed(ctx, lambda k: pplan.run(pout, check=False), 20)
-    ps = pplan.stats()
-    rs_bytes = 4 * (ps["source_pixels"] + sum(max(1, p["box"][2] - p["box"][0]) * max(1, p["box"][3] - p["box"][1])
-                                              for p in ppl))  # every cutout read once + every resampled pixel written once
-    result["placements_mode_lanczos"] = {
-        "ms_per_canvas_wall": round(e2 / 10 * 1e3, 3), "resample_ms": round(r2, 4), "composite_ms": round(c2, 4),
-        "Mpixels_per_s": round(W * H * 10 / e2 / 1e6, 1),
-        "composite_roofline_frac": frac(plan_bytes(ps), c2),
-        "resample_roofline": {"bound": "instruction issue (VALU + scalar), not hbm: profiles/r02_resample_experiments.txt",
-                              "algorithmic_bytes": rs_bytes, "achieved_GBps": round(rs_bytes / (r2 * 1e-3) / 1e9, 1),
-                              "frac_of_hbm_peak": frac(rs_bytes, r2)}}
-    del pplan, patlas
+    # ---- placements mode (direct composite() callers): Pillow-exact LANCZOS resample + overlaps.  "soft" =
+    # uniform random alpha in every pixel (the worst case for both kernels); "binary" = cutout-shaped alpha as in
+    # the reference's bundles (resampled layers are then soft only along their edges)
+    for key, amode in (("placements_mode_lanczos", "soft"), ("placements_mode_lanczos_binary_cutouts", "binary")):
+        psize, pobjs, ppl = synthetic.placements_workload(W, H, 32, 3, amode)
+        patlas = Atlas(pobjs)
+        pplan = CompositeBatch(patlas, [SolidCanvas(psize, synthetic.SOLID_BG)], [coerce_placements(patlas, ppl)])
+        pout = pplan.alloc_outputs()
+        for _ in range(3):
+            pplan.run(pout)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            pplan.run(pout, check=False)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t0
+        c2, r2 = bracketed(ctx, lambda k: pplan.run(pout, check=False), 20)
+        ps = pplan.stats()
+        rs_bytes = 4 * (ps["source_pixels"] + sum(max(1, p["box"][2] - p["box"][0]) * max(1, p["box"][3] - p["box"][1])
+                                                  for p in ppl))  # every cutout read once + every resampled pixel written once
+        result[key] = {
+            "alpha": amode, "ms_per_canvas_wall": round(e2 / 10 * 1e3, 3), "resample_ms": round(r2, 4),
+            "composite_ms": round(c2, 4), "Mpixels_per_s": round(W * H * 10 / e2 / 1e6, 1),
+            "composite_roofline_frac": frac(plan_bytes(ps), c2),
+            "resample_roofline": {"bound": "instruction issue (VALU + scalar), not hbm: profiles/r02_resample_experiments.txt",
+                                  "algorithmic_bytes": rs_bytes, "achieved_GBps": round(rs_bytes / (r2 * 1e-3) / 1e9, 1),
+                                  "frac_of_hbm_peak": frac(rs_bytes, r2)}}
+        del pplan, patlas
 
     # ---- PCIe-inclusive step: job-table upload + composite + D2H of every canvas into pinned memory
     # (SURVEY 8d's end-to-end figure; never `value`)

@@ -300,3 +300,69 @@ def test_raw_abi_contact_sheet(abi, golden_dir):
         assert lib.mic_contact_sheet(ctx, atlas, 0, None, 256, 256, 4, 72, 0, None, P(blank.data_ptr()), _stream()) == 0
         assert bool((blank == 255).all())
         assert lib.mic_atlas_destroy(atlas) == 0
+
+
+def test_raw_abi_edges_hardened_in_round_2(abi):
+    """Edges of the ABI tightened in round 2, one assertion each: an output that overlaps its background anywhere
+    (not just equal pointers) is refused; so are two canvases of one launch that overlap each other; a plan's cached
+    job table keeps refusing what it refused; work enqueued on a caller's (non-default) stream -- including the
+    atlas' planar copies, which used to be built on the NULL stream -- is ordered on that stream; plans and atlases
+    may be destroyed in any order."""
+    import torch
+    lib, ctx, nat = abi
+    rng = np.random.default_rng(3)
+    objs = {1: rng.integers(0, 256, (40, 60, 4), dtype=np.uint8), 2: rng.integers(0, 256, (33, 21, 4), dtype=np.uint8)}
+    atlas = _make_atlas(lib, ctx, objs)
+    atl = (P * 1)(atlas)
+    W, H = 128, 64
+    buf = torch.zeros(2 * W * H * 4, dtype=torch.uint8, device="cuda")
+    pl = (nat.Placement * 1)()
+    pl[0].atlas, pl[0].object_id = 0, 1
+    for k, v in enumerate((3, 3, 63, 43)):
+        pl[0].box[k] = v
+
+    def job(bg_off, out_off):
+        j = nat.Job()
+        j.width, j.height, j.n_placements, j.placements = W, H, 1, pl
+        j.bg_dev = buf.data_ptr() + bg_off if bg_off is not None else None
+        j.bg_rgba[3] = 255
+        j.out_dev = buf.data_ptr() + out_off
+        return j
+
+    # output = background shifted by one row: overlap, not equality
+    j = job(0, W * 4)
+    assert lib.mic_composite_batch(ctx, 1, atl, 1, ctypes.byref(j), 0, _stream()) < 0
+    assert b"overlaps the background" in lib.mic_last_error()
+    # two canvases of one launch, the second starting inside the first
+    jobs = (nat.Job * 2)(job(None, 0), job(None, W * H * 2))
+    assert lib.mic_composite_batch(ctx, 1, atl, 2, jobs, 0, _stream()) < 0
+    assert b"overlap" in lib.mic_last_error()
+    # a persistent plan refuses the bad output set every time it is offered (cached or not), and runs a good one
+    plan = P()
+    j = job(0, 0)
+    j.out_dev = None
+    assert lib.mic_plan_create(ctx, 1, atl, 1, ctypes.byref(j), 0, ctypes.byref(plan)) == 0, lib.mic_last_error()
+    bad = (P * 1)(buf.data_ptr() + 16)
+    good = (P * 1)(buf.data_ptr() + W * H * 4)
+    for _ in range(3):
+        assert lib.mic_plan_run(plan, bad, _stream()) < 0
+        assert lib.mic_plan_run(plan, good, _stream()) == 0, lib.mic_last_error()
+    # a resampling call on a side stream: planar copy + resample + composite are all ordered on that stream
+    side = torch.cuda.Stream()
+    out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    pl2 = (nat.Placement * 1)()
+    pl2[0].atlas, pl2[0].object_id = 0, 2
+    for k, v in enumerate((10, 5, 10 + 50, 5 + 44)):  # 21x33 -> 50x44: LANCZOS
+        pl2[0].box[k] = v
+    j2 = nat.Job()
+    j2.width, j2.height, j2.n_placements, j2.placements, j2.out_dev = W, H, 1, pl2, out.data_ptr()
+    for k, v in enumerate((9, 200, 33, 255)):
+        j2.bg_rgba[k] = v
+    with torch.cuda.stream(side):
+        assert lib.mic_composite_batch(ctx, 1, atl, 1, ctypes.byref(j2), 0, P(side.cuda_stream)) == 0, lib.mic_last_error()
+    side.synchronize()
+    want = oracle.composite(oracle.fill_solid((W, H), (9, 200, 33, 255)), objs, [{"object_id": 2, "box": [10, 5, 60, 49]}])
+    assert np.array_equal(out.cpu().numpy(), want)
+    # destroy order: the atlas first, then the plan that was made from it
+    assert lib.mic_atlas_destroy(atlas) == 0
+    assert lib.mic_plan_destroy(plan) == 0
