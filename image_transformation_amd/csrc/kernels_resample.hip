@@ -369,45 +369,58 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
     const int c_lo = hmeta[xt0][0];  // the strip's first source column (a multiple of 16)
     // 16-byte column chunks of a band: what the strip's tiles can touch, inside the cutout's padded rows
     const int n16 = min(J.pitch_c >> 4, (J.planar_pitch - c_lo) >> 4);
-    const int plane_s = 16 * J.pitch_c, plane_r = 64 * J.pitch_r;
-    uint8_t *srcP = lds8;                 // [4][16][pitch_c]   the source band
-    uint8_t *ring = lds8 + 4 * plane_s;   // [4][64][pitch_r]   intermediate rows, 16-row slots
+    const int plane_s = 16 * J.pitch_c;
+    uint8_t *srcP = lds8;                 // [4][16][pitch_c]     the source band
+    // intermediate rows: [x 64][ring16 slots of 16 rows][channel 4][16 rows] -- the four channels of a slot lie 16
+    // bytes apart, so one address register serves all four (instruction offsets); a column is pitch_r =
+    // 64 ring16 + 16 bytes (the 16 spread the columns over the banks)
+    uint8_t *ring = lds8 + 4 * plane_s;
     const int rmask = J.ring16 - 1;
     const int band0 = vmeta[yt0][0] >> 4;                  // window starts are multiples of 16
     const int band_last = (vmeta[yt0 + n_yt - 1][3] - 1) >> 4;
 
     // ---- this wave's x-tile: horizontal taps stay in registers for the whole unit
     const bool active = wave < n_xt;  // wave-uniform
-    const v4i hm_v = hmeta[xt0 + (active ? wave : 0)];  // the same for every lane: kept in scalar registers
+    const int xt = xt0 + (active ? wave : 0);
+    const v4i hm_v = hmeta[xt];  // the same for every lane: kept in scalar registers
     const int hm[3] = {__builtin_amdgcn_readfirstlane(hm_v[0]), __builtin_amdgcn_readfirstlane(hm_v[1]),
                        __builtin_amdgcn_readfirstlane(hm_v[2])};
+    const uint32_t lane16 = (uint32_t)lane * 16u, l15x4 = (uint32_t)l15 * 4u;
     // (- 128 << 22: the horizontal pass clips to signed bytes, see clip8x4_signed)
-    const int hb = reinterpret_cast<gciptr>(J.hbias)[(xt0 + (active ? wave : 0)) * 16 + l15] - (128 << 22);
+    const int hb = *reinterpret_cast<gciptr>(J.hbias + (uint64_t)xt * 64 + l15x4) - (128 << 22);
     const v4i hbias = {hb, hb, hb, hb};
-    gv4ptr hfbase = reinterpret_cast<gv4ptr>(J.hfrag) + (size_t)hm[2] * 3 * 64 + lane;
+    // (uniform 64-bit base + 32-bit lane offset: the loads take the scalar-base addressing form, no 64-bit
+    // vector address arithmetic)
+    const uint64_t hfb = J.hfrag + (uint64_t)hm[2] * 3072;
+    gv4ptr hfbase = reinterpret_cast<gv4ptr>(hfb + lane16);
     const v4i hf[3] = {hfbase[0], hfbase[64], hfbase[128]};
     const uint8_t *a0 = srcP + l15 * J.pitch_c + (hm[0] - c_lo) + 16 * lh;
-    uint8_t *m0 = ring + (wave * 16 + l15) * J.pitch_r + 4 * lh;
-    const uint8_t *r0 = ring + (wave * 16 + l15) * J.pitch_r;
+    uint8_t *m0 = ring + (wave * 16 + l15) * J.pitch_r + 4 * lh;  // + 64 slot + 16 c
+    const uint8_t *r0 = ring + (wave * 16 + l15) * J.pitch_r;     // + 64 slot + 16 c
     gptr dst = reinterpret_cast<gptr>(J.dst);
     const int ox = (xt0 + wave) * 16 + 4 * lh;
+    const bool x_full = (xt0 + wave) * 16 + 16 <= J.dw;   // wave-uniform: every lane's 4 pixels are inside the row
+    const uint32_t lane_idx = (uint32_t)(l15 * J.dw + ox);  // pixel index of this lane inside a tile of output rows
+    const bool ox_ok = ox < J.dw;
 
     // ---- band loader: wave = plane, lane = (row, chunk mod 4); chunks cl, cl + 4, ... < n16
     const int lrow = lane >> 2, cl = lane & 3;
-    const uint64_t gplane = J.src + (uint64_t)wave * ((uint64_t)J.planar_pitch * J.sh) + c_lo + 16 * cl;
+    const uint64_t gplane = J.src + (uint64_t)wave * ((uint64_t)J.planar_pitch * J.sh) + c_lo;  // uniform
     uint8_t *lds_dst = srcP + wave * plane_s + lrow * J.pitch_c + 16 * cl;
     v4i pre[2];
-    auto band_row = [&](int b) { return gplane + (uint64_t)min(16 * b + lrow, J.sh - 1) * J.planar_pitch; };
+    // byte offset of this lane's first chunk of band b inside the plane (a plane is < 2^31 bytes)
+    auto band_off = [&](int b) { return (uint32_t)min(16 * b + lrow, J.sh - 1) * (uint32_t)J.planar_pitch + 16u * cl; };
     auto prefetch = [&](int b) {
-        const uint64_t g = band_row(b);
+        const uint32_t o = band_off(b);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-            if (cl + 4 * k < n16) pre[k] = *reinterpret_cast<gv4ptr>(g + 64 * k);
+            if (cl + 4 * k < n16) pre[k] = *reinterpret_cast<gv4ptr>(gplane + (o + 64u * k));
     };
     prefetch(band0);
 
     int yt = 0;           // next tile of output rows (relative to yt0) to emit
     uint32_t zmask = 0;   // bit s: ring slot s holds an all-zero band
+    const uint32_t ring_bits = (1u << J.ring16) - 1u;
     for (int b = band0; b <= band_last; ++b) {
         __syncthreads();  // every wave is done reading the previous band
         {
@@ -423,9 +436,9 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                         seen |= (uint32_t)((pre[k][0] ^ k80) | (pre[k][1] ^ k80) | (pre[k][2] ^ k80) | (pre[k][3] ^ k80));
             }
             if (n16 > 8) {  // strips of deep shrinks: the rest of the band, not prefetched
-                const uint64_t g = band_row(b);
+                const uint32_t o = band_off(b);
                 for (int k = 2; cl + 4 * k < n16; ++k) {
-                    const v4i v = *reinterpret_cast<gv4ptr>(g + 64 * k);
+                    const v4i v = *reinterpret_cast<gv4ptr>(gplane + (o + 64u * k));
                     *reinterpret_cast<v4i *>(lds_dst + 64 * k) = v;
                     seen |= (uint32_t)((v[0] ^ k80) | (v[1] ^ k80) | (v[2] ^ k80) | (v[3] ^ k80));
                 }
@@ -440,11 +453,12 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
         const bool zero_band = __builtin_amdgcn_readfirstlane((int)band_alpha) == 0;
         const int slot = b & rmask;
         if (active) {
+            uint8_t *m = m0 + 64 * slot;
             if (zero_band) {
                 // premultiplied zeros in, clip8(2^21 >> 22) = 0 out: the intermediate rows are zero
                 zmask |= 1u << slot;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m0 + 16 * slot + c * plane_r) = 0x80808080u;
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m + 16 * c) = 0x80808080u;
             } else {
                 zmask &= ~(1u << slot);
                 // D[row = 4 lh + reg (band row)][col = l15 (x)]: 4 consecutive rows of one column
@@ -453,7 +467,7 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                 if (hm[1] == 1) tile4<true, true>(load, hf, hfbase, 1, hbias, w);
                 else tile4<false, true>(load, hf, hfbase, hm[1], hbias, w);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m0 + 16 * slot + c * plane_r) = w[c];
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m + 16 * c) = w[c];
             }
         }
         // ---- tiles of output rows whose last tap row is now in the ring
@@ -463,22 +477,25 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
             const int v_frag = __builtin_amdgcn_readfirstlane(vm[2]), v_hi = __builtin_amdgcn_readfirstlane(vm[3]);
             if (v_hi > 16 * (b + 1)) break;
             if (active) {
-                const int oy = (yt0 + yt) * 16 + l15;
-                const bool inside = oy < J.dh && ox < J.dw;
-                const uint32_t o_idx = (uint32_t)(oy * J.dw + ox);  // < 2^30 px
-                bool all_zero = true;
-                for (int s = v_ws >> 4; s <= (v_hi - 1) >> 4; ++s) all_zero = all_zero && ((zmask >> (s & rmask)) & 1u);
+                const int row0 = (yt0 + yt) * 16;  // first output row of the tile (scalar)
+                const bool inside = ox_ok && l15 < J.dh - row0;
+                const uint32_t o_idx = (uint32_t)(row0 * J.dw) + lane_idx;  // < 2^30 px
+                // every 16-row slot of the tile's window holds zeros? (window slots as a bit mask, rotated into the ring)
+                const int s_first = (v_ws >> 4) & rmask, n_slots = ((v_hi - 1) >> 4) - (v_ws >> 4) + 1;
+                uint32_t need = ((1u << n_slots) - 1u) << s_first;
+                need = (need | (need >> J.ring16)) & ring_bits;
+                const bool all_zero = (zmask & need) == need;
                 u32x4 px = {0u, 0u, 0u, 0u};
                 if (!all_zero) {
-                    const int vb = reinterpret_cast<gciptr>(J.vbias)[(yt0 + yt) * 16 + l15];
+                    const int vb = *reinterpret_cast<gciptr>(J.vbias + (uint64_t)row0 * 4 + l15x4);
                     const v4i vbias = {vb, vb, vb, vb};
-                    gv4ptr vfbase = reinterpret_cast<gv4ptr>(J.vfrag) + (size_t)v_frag * 3 * 64 + lane;
+                    gv4ptr vfbase = reinterpret_cast<gv4ptr>(J.vfrag + (uint64_t)v_frag * 3072 + lane16);
                     const v4i vf[3] = {vfbase[0], vfbase[64], vfbase[128]};
                     const int base16 = (v_ws >> 4) + lh;
                     uint32_t w[4];
                     // A[m = l15 (x)][k = 16 lh + j (window row)]; D[row = 4 lh + reg (x)][col = l15 (output row)]
                     auto load = [&](int c, int ch) {
-                        return *reinterpret_cast<const v4i *>(r0 + c * plane_r + (((base16 + 4 * ch) & rmask) << 4));
+                        return *reinterpret_cast<const v4i *>(r0 + (((base16 + 4 * ch) & rmask) << 6) + 16 * c);
                     };
                     if (v_nch == 1) tile4<true, false>(load, vf, vfbase, 1, vbias, w);
                     else tile4<false, false>(load, vf, vfbase, v_nch, vbias, w);
@@ -487,14 +504,12 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                     const bool soft = (w[3] & 0x7F7F7F7Fu) != (top << 7) - top;
                     px = __any(soft) ? unpremultiply4(w, recip) : interleave4(w);
                 }
-                if (inside) {
-                    if (ox + 4 <= J.dw) {
-                        *reinterpret_cast<MIC_GLOBAL u32x4_a4 *>(dst + o_idx) = px;
-                    } else {
+                if (x_full) {  // (wave-uniform) one 16-byte store per lane
+                    if (inside) *reinterpret_cast<MIC_GLOBAL u32x4_a4 *>(dst + o_idx) = px;
+                } else if (inside) {
 #pragma unroll
-                        for (int j = 0; j < 3; ++j)
-                            if (ox + j < J.dw) dst[o_idx + j] = px[j];
-                    }
+                    for (int j = 0; j < 4; ++j)
+                        if (ox + j < J.dw) dst[o_idx + j] = px[j];
                 }
             }
             ++yt;

@@ -630,7 +630,7 @@ int choose_march(mic_ctx *ctx, ResizePlan *p, int filter) {
     int ring16 = 4;
     while (ring16 < slots) ring16 *= 2;
     if (ring16 > 32) return MIC_OK;  // the kernel tracks empty ring slots in a 32-bit mask
-    const int pitch_r = 16 * ring16 + 16;
+    const int pitch_r = 64 * ring16 + 16;  // per column: ring16 slots x 4 channels x 16 rows, + 16 to spread the banks
     if (rs_march_lds_bytes(pitch_c, pitch_r) > kRsMarchMaxLds) return MIC_OK;
     p->march = true; p->pitch_c = pitch_c; p->ring16 = ring16; p->pitch_r = pitch_r;
     return MIC_OK;

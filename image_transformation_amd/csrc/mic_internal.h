@@ -85,7 +85,7 @@ struct alignas(16) RsMarch {
     int32_t tiles_x, tiles_y;      // 16-sample tiles per axis
     int32_t strips, segs, seg_tiles;
     int32_t pitch_c;               // LDS bytes per row of a source band plane: what a strip's tiles can touch
-    int32_t ring16, pitch_r;       // ring of intermediate rows: 16-row slots (a power of two), bytes per column
+    int32_t ring16, pitch_r;       // ring of intermediate rows: 16-row slots (a power of two), bytes per column (64 ring16 + 16)
     // A layer with more than kRsUnitsPerEntry units takes several table entries (grid.y); workgroup
     // bx of entry e works on unit ((bx + xcd_rot) & 7) * 4 n_entries + 4 e + (bx >> 3): workgroups
     // are dealt round-robin over the 8 XCDs, so each XCD gets a contiguous run of the layer's units
@@ -95,7 +95,8 @@ struct alignas(16) RsMarch {
 static_assert(sizeof(RsMarch) == 128, "RsMarch layout");
 constexpr int kRsMaxSegTiles = 64;                 // tiles of 16 output rows per unit, at most
 inline size_t rs_march_lds_bytes(int pitch_c, int pitch_r) {
-    return 4 * ((size_t)16 * pitch_c + (size_t)64 * pitch_r) + 64;  // + slack for chunk over-reads
+    // source band: 4 planes x 16 rows x pitch_c; ring: 64 columns x pitch_r (ring16 slots x 4 channels x 16 rows + 16)
+    return (size_t)4 * 16 * pitch_c + (size_t)64 * pitch_r + 64;  // + slack for chunk over-reads
 }
 // Occupancy is what this kernel lives on (it is bound by vector issue): layers whose unit fits this much
 // LDS run 5 workgroups per CU; bigger windows (shrinks below ~1/2) go to a second launch.
