@@ -348,6 +348,16 @@ __device__ __forceinline__ u32x4 interleave4(const uint32_t (&w)[4]) {
                  byte_perm(ba23, rg23, 0x05040100u), byte_perm(ba23, rg23, 0x07060302u)};
 }
 
+// uniform 64-bit base + 32-bit per-lane byte offset, written as pointer arithmetic so that the load takes
+// the scalar-base addressing form (global_load v, v_off, s[base:base+1]) instead of 64-bit vector address maths
+template <class T>
+__device__ __forceinline__ const MIC_GLOBAL T *at(uint64_t base, uint32_t byte_off) {
+    return reinterpret_cast<const MIC_GLOBAL T *>(reinterpret_cast<const MIC_GLOBAL char *>(base) + byte_off);
+}
+
+// ONE_CHUNK: every tile of both axes has its taps inside one 64-sample window (any scale down to ~1/3: what the
+// host checks per layer) -- the instantiation without the chunk loops, their registers and their branches.
+template <bool ONE_CHUNK>
 __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const RsMarch *__restrict__ jobs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
     __shared__ float recip[256];            // unpremultiply factors 255/a: an LDS read per pixel
@@ -387,12 +397,12 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                        __builtin_amdgcn_readfirstlane(hm_v[2])};
     const uint32_t lane16 = (uint32_t)lane * 16u, l15x4 = (uint32_t)l15 * 4u;
     // (- 128 << 22: the horizontal pass clips to signed bytes, see clip8x4_signed)
-    const int hb = *reinterpret_cast<gciptr>(J.hbias + (uint64_t)xt * 64 + l15x4) - (128 << 22);
+    const int hb = *at<int32_t>(J.hbias + (uint64_t)xt * 64, l15x4) - (128 << 22);
     const v4i hbias = {hb, hb, hb, hb};
     // (uniform 64-bit base + 32-bit lane offset: the loads take the scalar-base addressing form, no 64-bit
     // vector address arithmetic)
     const uint64_t hfb = J.hfrag + (uint64_t)hm[2] * 3072;
-    gv4ptr hfbase = reinterpret_cast<gv4ptr>(hfb + lane16);
+    gv4ptr hfbase = at<v4i>(hfb, lane16);
     const v4i hf[3] = {hfbase[0], hfbase[64], hfbase[128]};
     const uint8_t *a0 = srcP + l15 * J.pitch_c + (hm[0] - c_lo) + 16 * lh;
     uint8_t *m0 = ring + (wave * 16 + l15) * J.pitch_r + 4 * lh;  // + 64 slot + 16 c
@@ -414,11 +424,22 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
         const uint32_t o = band_off(b);
 #pragma unroll
         for (int k = 0; k < 2; ++k)
-            if (cl + 4 * k < n16) pre[k] = *reinterpret_cast<gv4ptr>(gplane + (o + 64u * k));
+            if (cl + 4 * k < n16) pre[k] = *at<v4i>(gplane, o + 64u * k);
     };
     prefetch(band0);
 
-    int yt = 0;           // next tile of output rows (relative to yt0) to emit
+    int yt = 0;           // next tile of output rows (relative to yt0) to emit ...
+    int v_ws = 0, v_nch = 1, v_frag = 0, v_hi = 0;  // ... and its table entry (window start, chunks, taps, window end)
+    auto next_tile = [&]() {
+        const v4i vm = yt < n_yt ? vm_lds[yt] : v4i{0, 1, 0, 0};
+        v_ws = __builtin_amdgcn_readfirstlane(vm[0]); v_nch = __builtin_amdgcn_readfirstlane(vm[1]);
+        v_frag = __builtin_amdgcn_readfirstlane(vm[2]); v_hi = __builtin_amdgcn_readfirstlane(vm[3]);
+    };
+    {
+        const v4i vm = vmeta[yt0];  // (the first entry straight from memory: vm_lds is not visible before the first barrier)
+        v_ws = __builtin_amdgcn_readfirstlane(vm[0]); v_nch = __builtin_amdgcn_readfirstlane(vm[1]);
+        v_frag = __builtin_amdgcn_readfirstlane(vm[2]); v_hi = __builtin_amdgcn_readfirstlane(vm[3]);
+    }
     uint32_t zmask = 0;   // bit s: ring slot s holds an all-zero band
     const uint32_t ring_bits = (1u << J.ring16) - 1u;
     for (int b = band0; b <= band_last; ++b) {
@@ -435,10 +456,10 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                     if (cl + 4 * k < n16)
                         seen |= (uint32_t)((pre[k][0] ^ k80) | (pre[k][1] ^ k80) | (pre[k][2] ^ k80) | (pre[k][3] ^ k80));
             }
-            if (n16 > 8) {  // strips of deep shrinks: the rest of the band, not prefetched
+            if (n16 > 8) {  // wide strips (shrinks below ~1/1.3): the rest of the band, not prefetched
                 const uint32_t o = band_off(b);
                 for (int k = 2; cl + 4 * k < n16; ++k) {
-                    const v4i v = *reinterpret_cast<gv4ptr>(gplane + (o + 64u * k));
+                    const v4i v = *at<v4i>(gplane, o + 64u * k);
                     *reinterpret_cast<v4i *>(lds_dst + 64 * k) = v;
                     seen |= (uint32_t)((v[0] ^ k80) | (v[1] ^ k80) | (v[2] ^ k80) | (v[3] ^ k80));
                 }
@@ -464,18 +485,15 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                 // D[row = 4 lh + reg (band row)][col = l15 (x)]: 4 consecutive rows of one column
                 uint32_t w[4];
                 auto load = [&](int c, int ch) { return *reinterpret_cast<const v4i *>(a0 + c * plane_s + 64 * ch); };
-                if (hm[1] == 1) tile4<true, true>(load, hf, hfbase, 1, hbias, w);
+                if (ONE_CHUNK || hm[1] == 1) tile4<true, true>(load, hf, hfbase, 1, hbias, w);
                 else tile4<false, true>(load, hf, hfbase, hm[1], hbias, w);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m + 16 * c) = w[c];
             }
         }
-        // ---- tiles of output rows whose last tap row is now in the ring
-        while (yt < n_yt) {
-            const v4i vm = vm_lds[yt];
-            const int v_ws = __builtin_amdgcn_readfirstlane(vm[0]), v_nch = __builtin_amdgcn_readfirstlane(vm[1]);
-            const int v_frag = __builtin_amdgcn_readfirstlane(vm[2]), v_hi = __builtin_amdgcn_readfirstlane(vm[3]);
-            if (v_hi > 16 * (b + 1)) break;
+        // ---- tiles of output rows whose last tap row is now in the ring (the next tile's table entry waits in
+        // scalar registers: a band that completes no tile costs one compare)
+        while (yt < n_yt && v_hi <= 16 * (b + 1)) {
             if (active) {
                 const int row0 = (yt0 + yt) * 16;  // first output row of the tile (scalar)
                 const bool inside = ox_ok && l15 < J.dh - row0;
@@ -487,9 +505,9 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                 const bool all_zero = (zmask & need) == need;
                 u32x4 px = {0u, 0u, 0u, 0u};
                 if (!all_zero) {
-                    const int vb = *reinterpret_cast<gciptr>(J.vbias + (uint64_t)row0 * 4 + l15x4);
+                    const int vb = *at<int32_t>(J.vbias + (uint64_t)row0 * 4, l15x4);
                     const v4i vbias = {vb, vb, vb, vb};
-                    gv4ptr vfbase = reinterpret_cast<gv4ptr>(J.vfrag + (uint64_t)v_frag * 3072 + lane16);
+                    gv4ptr vfbase = at<v4i>(J.vfrag + (uint64_t)v_frag * 3072, lane16);
                     const v4i vf[3] = {vfbase[0], vfbase[64], vfbase[128]};
                     const int base16 = (v_ws >> 4) + lh;
                     uint32_t w[4];
@@ -497,7 +515,7 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                     auto load = [&](int c, int ch) {
                         return *reinterpret_cast<const v4i *>(r0 + (((base16 + 4 * ch) & rmask) << 6) + 16 * c);
                     };
-                    if (v_nch == 1) tile4<true, false>(load, vf, vfbase, 1, vbias, w);
+                    if (ONE_CHUNK || v_nch == 1) tile4<true, false>(load, vf, vfbase, 1, vbias, w);
                     else tile4<false, false>(load, vf, vfbase, v_nch, vbias, w);
                     // alpha bytes all 0 or 255 <=> low 7 bits of every byte equal its top bit
                     const uint32_t top = (w[3] >> 7) & 0x01010101u;
@@ -513,34 +531,39 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                 }
             }
             ++yt;
+            next_tile();
         }
     }
 }
 
-// jobs_dev[0, n_small) need at most kRsSmallLds bytes of LDS (several workgroups per CU), the rest more.
-hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, int n_small, size_t lds_small, size_t lds_large,
+// jobs_dev[0, n_fast): layers whose tiles all fit one 64-sample chunk per axis (the lean instantiation, lds_fast
+// bytes of LDS); the rest: the general one (lds_rest).
+hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, int n_fast, size_t lds_fast, size_t lds_rest,
                                  hipStream_t stream) {
     if (n_jobs <= 0) return hipSuccess;
-    // opt the kernel in for more than 64 KB of dynamic LDS, once per device of this process
+    // opt the kernels in for more than 64 KB of dynamic LDS, once per device of this process
     // (atomic flags: two threads racing here both set the same attribute, which is harmless)
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_march_kernel),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_march_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsMarchMaxLds);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_march_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsMarchMaxLds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
-    for (int first = 0; first < n_small; first += 65535) {  // grid.y limit
-        const int n = std::min(65535, n_small - first);
-        hipLaunchKernelGGL(resample_march_kernel, dim3((unsigned)kRsUnitsPerEntry, (unsigned)n), dim3(256), lds_small,
+    for (int first = 0; first < n_fast; first += 65535) {  // grid.y limit
+        const int n = std::min(65535, n_fast - first);
+        hipLaunchKernelGGL(resample_march_kernel<true>, dim3((unsigned)kRsUnitsPerEntry, (unsigned)n), dim3(256), lds_fast,
                            stream, jobs_dev + first);
     }
-    for (int first = n_small; first < n_jobs; first += 65535) {
+    for (int first = n_fast; first < n_jobs; first += 65535) {
         const int n = std::min(65535, n_jobs - first);
-        hipLaunchKernelGGL(resample_march_kernel, dim3((unsigned)kRsUnitsPerEntry, (unsigned)n), dim3(256), lds_large,
+        hipLaunchKernelGGL(resample_march_kernel<false>, dim3((unsigned)kRsUnitsPerEntry, (unsigned)n), dim3(256), lds_rest,
                            stream, jobs_dev + first);
     }
     return hipGetLastError();

@@ -138,6 +138,7 @@ struct FragBuffer {
 };
 struct FragEntry {
     int tiles = 0;
+    int max_chunks = 0;  // most 64-sample chunks any tile's window has
     std::shared_ptr<FragBuffer> buf;  // meta | bias | frags
     uint64_t meta = 0, bias = 0, frags = 0;
     std::shared_ptr<std::vector<int32_t>> meta_host;  // [tiles][4], for sizing the LDS windows
@@ -350,6 +351,7 @@ static int get_frags(mic_ctx *ctx, int in, int out, int filter, FragEntry *res) 
     const AxisFrags f = build_axis_frags(in == out ? identity_axis_table(in) : build_axis_table(in, out, filter));
     FragEntry e;
     e.tiles = f.tiles;
+    e.max_chunks = f.max_chunks;
     const size_t meta_b = align_up(f.meta.size() * sizeof(int32_t), 64);
     const size_t bias_b = align_up(f.bias.size() * sizeof(int32_t), 64);
     e.buf = std::make_shared<FragBuffer>();
@@ -582,6 +584,7 @@ struct ResizePlan {
     uint64_t dst_ptr = 0; // caller-provided destination (mic_resize)
     // marching MFMA kernel (source band + ring of intermediate rows in LDS); march == false: two-pass fallback
     bool march = false;
+    bool one_chunk = false;  // every tile of both axes has one 64-sample chunk: the lean kernel instantiation
     int pitch_c = 0, ring16 = 0, pitch_r = 0;
     uint64_t planar_src = 0;  // the source's planar premultiplied copy (atlas copy, or arena scratch for mic_resize)
     int planar_pitch = 0;
@@ -591,8 +594,9 @@ struct PassTables {
     std::vector<RsMarch> fused;
     std::vector<std::shared_ptr<FragBuffer>> frag_refs;  // keeps the tables `fused` points into alive
     int fused_layers = 0;
-    int fused_small = 0;  // entries [0, fused_small) fit kRsMarchSmallLds, the rest need more LDS
-    size_t lds_small = 0, lds_large = 0;
+    std::vector<uint8_t> fused_fast;  // per entry of `fused` (until they are sorted): one-chunk layer
+    int fused_n_fast = 0;             // entries [0, fused_n_fast) run the one-chunk instantiation, the rest the general one
+    size_t lds_fast = 0, lds_rest = 0;
     std::vector<RsJob> h, v;
     int max_h_out_w = 0, max_h_rows = 0, max_v_out_w = 0, max_v_out_h = 0;
 };
@@ -633,6 +637,7 @@ int choose_march(mic_ctx *ctx, ResizePlan *p, int filter) {
     const int pitch_r = 64 * ring16 + 16;  // per column: ring16 slots x 4 channels x 16 rows, + 16 to spread the banks
     if (rs_march_lds_bytes(pitch_c, pitch_r) > kRsMarchMaxLds) return MIC_OK;
     p->march = true; p->pitch_c = pitch_c; p->ring16 = ring16; p->pitch_r = pitch_r;
+    p->one_chunk = fh.max_chunks == 1 && fv.max_chunks == 1;
     return MIC_OK;
 }
 
@@ -682,10 +687,13 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             const int n_units = f.strips * f.segs;
             f.n_entries = (n_units + kRsUnitsPerEntry - 1) / kRsUnitsPerEntry;
             f.xcd_rot = pt->fused_layers++ & 7;  // the XCD that gets a layer's short last run rotates
-            for (f.entry = 0; f.entry < f.n_entries; ++f.entry) pt->fused.push_back(f);
+            for (f.entry = 0; f.entry < f.n_entries; ++f.entry) {
+                pt->fused.push_back(f);
+                pt->fused_fast.push_back(p.one_chunk ? 1 : 0);
+            }
             const size_t lds = rs_march_lds_bytes(f.pitch_c, f.pitch_r);
-            if (lds <= kRsMarchSmallLds) pt->lds_small = std::max(pt->lds_small, lds);
-            else pt->lds_large = std::max(pt->lds_large, lds);
+            if (p.one_chunk) pt->lds_fast = std::max(pt->lds_fast, lds);
+            else pt->lds_rest = std::max(pt->lds_rest, lds);
             continue;
         }
         uint64_t v_src = p.src;
@@ -723,17 +731,13 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             pt->max_v_out_h = std::max(pt->max_v_out_h, p.dh);
         }
     }
-    // Entries with small LDS first (more workgroups per CU), the rest after, as two launches -- unless the
-    // rest is modest too: a second launch of a few entries is a serial tail (one unit's latency, ~20 us)
-    // that costs more than running everything at the larger size.
-    if (pt->lds_large > 0 && pt->lds_large <= kRsMarchMergeLds) {
-        pt->lds_small = std::max(pt->lds_small, pt->lds_large);
-        pt->lds_large = 0;
-        pt->fused_small = (int)pt->fused.size();
-        return MIC_OK;
-    }
-    auto small = [](const RsMarch &f) { return rs_march_lds_bytes(f.pitch_c, f.pitch_r) <= kRsMarchSmallLds; };
-    pt->fused_small = (int)(std::stable_partition(pt->fused.begin(), pt->fused.end(), small) - pt->fused.begin());
+    // one-chunk layers first (the lean instantiation), the general ones after: at most two launches
+    std::vector<RsMarch> fast, rest;
+    for (size_t i = 0; i < pt->fused.size(); ++i) (pt->fused_fast[i] ? fast : rest).push_back(pt->fused[i]);
+    pt->fused_n_fast = (int)fast.size();
+    pt->fused = std::move(fast);
+    pt->fused.insert(pt->fused.end(), rest.begin(), rest.end());
+    pt->fused_fast.clear();
     return MIC_OK;
 }
 
@@ -1062,7 +1066,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], stream));
     HIP_TRY(launch_resample_march(reinterpret_cast<const RsMarch *>(dp + P->off_f), (int)P->pt.fused.size(),
-                                   P->pt.fused_small, P->pt.lds_small, P->pt.lds_large, stream));
+                                   P->pt.fused_n_fast, P->pt.lds_fast, P->pt.lds_rest, stream));
     HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + P->off_h), (int)P->pt.h.size(),
                               P->pt.max_h_out_w, P->pt.max_h_rows, stream));
     HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + P->off_v), (int)P->pt.v.size(),
@@ -1348,7 +1352,7 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
         HIP_TRY(launch_planarize(reinterpret_cast<const PlanarJob *>(dp + off_p), 1,
                                  (int64_t)(rp.planar_pitch / 4) * src_h, stream));
     HIP_TRY(launch_resample_march(reinterpret_cast<const RsMarch *>(dp + off_f), (int)pt.fused.size(),
-                                   pt.fused_small, pt.lds_small, pt.lds_large, stream));
+                                   pt.fused_n_fast, pt.lds_fast, pt.lds_rest, stream));
     HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp), (int)pt.h.size(), pt.max_h_out_w,
                               pt.max_h_rows, stream));
     HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + off_v), (int)pt.v.size(), pt.max_v_out_w,

@@ -98,10 +98,6 @@ inline size_t rs_march_lds_bytes(int pitch_c, int pitch_r) {
     // source band: 4 planes x 16 rows x pitch_c; ring: 64 columns x pitch_r (ring16 slots x 4 channels x 16 rows + 16)
     return (size_t)4 * 16 * pitch_c + (size_t)64 * pitch_r + 64;  // + slack for chunk over-reads
 }
-// Occupancy is what this kernel lives on (it is bound by vector issue): layers whose unit fits this much
-// LDS run 5 workgroups per CU; bigger windows (shrinks below ~1/2) go to a second launch.
-constexpr size_t kRsMarchSmallLds = 30000;  // + ~2 KB of static LDS: five per 160 KB
-constexpr size_t kRsMarchMergeLds = 38 * 1024;    // up to here one launch serves both classes (4 per CU)
 constexpr size_t kRsMarchMaxLds = 150 * 1024;      // last resort before the two-pass fallback
 constexpr int kRsUnitsPerEntry = 32;
 #ifndef MIC_RS_WAVES
@@ -126,7 +122,7 @@ struct alignas(16) PlanarJob {
 };
 static_assert(sizeof(PlanarJob) == 32, "PlanarJob layout");
 hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream);
-hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, int n_small, size_t lds_small, size_t lds_large,
+hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, int n_fast, size_t lds_fast, size_t lds_rest,
                                  hipStream_t stream);
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);
 // table_dev: scratch for max(W, H) <= 65535 colours (kGradientTableWords uint32)
