@@ -175,6 +175,9 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const RsJob *__restrict
 // The k index of both operands is defined by the same (lane >> 4, byte) -> window position map, so
 // the result does not depend on the hardware's internal k order; C/D follow the documented
 // col = lane & 15, row = 4 (lane >> 4) + reg map.  Bit-exact with the two-pass kernels above.
+#ifndef MIC_RS_CHAINS
+#define MIC_RS_CHAINS 4
+#endif
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) v4i *gv4ptr;
@@ -228,6 +231,25 @@ template <bool SINGLE, bool SIGNED, class Load>
 __device__ __forceinline__ void tile4(Load load, const v4i (&f)[3], gv4ptr fbase, int n_chunks, v4i bias,
                                       uint32_t (&w)[4]) {
     if (SINGLE) {
+#if MIC_RS_CHAINS == 4
+        // all four channels' chains side by side: each MFMA's result is needed three MFMAs later, so the
+        // dependent shifts need no s_nop padding (registers: 4 x (operand + accumulator))
+        v4i a[4], acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[c] = load(c, 0);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[c], f[d], d == 0 ? bias : acc[c], 0, 0, 0);
+            if (d < 2) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = shr8(acc[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[c] = SIGNED ? clip8x4_signed(acc[c]) : clip8x4(acc[c]);
+#else
         // two channels at a time: 2 x (operand + accumulator) live instead of 4 x (this kernel's register
         // budget is what sets its occupancy), still two independent chains to hide each other's latency
 #pragma unroll
@@ -246,6 +268,7 @@ __device__ __forceinline__ void tile4(Load load, const v4i (&f)[3], gv4ptr fbase
             w[c0] = SIGNED ? clip8x4_signed(x) : clip8x4(x);
             w[c0 + 1] = SIGNED ? clip8x4_signed(y) : clip8x4(y);
         }
+#endif
     } else {
         v4i acc[4];
 #pragma unroll
