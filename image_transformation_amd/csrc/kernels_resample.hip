@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
         v_frag = __builtin_amdgcn_readfirstlane(vm[2]); v_hi = __builtin_amdgcn_readfirstlane(vm[3]);
     }
     uint32_t zmask = 0;   // bit s: ring slot s holds an all-zero band
-    const uint32_t ring_bits = (1u << J.ring16) - 1u;
+    const uint32_t ring_bits = (uint32_t)((1ull << J.ring16) - 1ull);
     for (int b = band0; b <= band_last; ++b) {
         __syncthreads();  // every wave is done reading the previous band
         {
@@ -523,8 +523,9 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                 const uint32_t o_idx = (uint32_t)(row0 * J.dw) + lane_idx;  // < 2^30 px
                 // every 16-row slot of the tile's window holds zeros? (window slots as a bit mask, rotated into the ring)
                 const int s_first = (v_ws >> 4) & rmask, n_slots = ((v_hi - 1) >> 4) - (v_ws >> 4) + 1;
-                uint32_t need = ((1u << n_slots) - 1u) << s_first;
-                need = (need | (need >> J.ring16)) & ring_bits;
+                // (64-bit: a ring of 32 slots makes these shifts reach 32 bits and beyond)
+                const uint64_t span = ((1ull << n_slots) - 1ull) << s_first;
+                const uint32_t need = (uint32_t)(span | (span >> J.ring16)) & ring_bits;
                 const bool all_zero = (zmask & need) == need;
                 u32x4 px = {0u, 0u, 0u, 0u};
                 if (!all_zero) {

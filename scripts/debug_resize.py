@@ -16,17 +16,19 @@ ctx = _native.context(0)
 rng = np.random.default_rng(7)
 shapes = [((64, 64), (64, 48)), ((64, 64), (48, 64)), ((64, 64), (80, 80)), ((301, 203), (457, 311)),
           ((457, 311), (301, 203)), ((1000, 800), (256, 205)), ((130, 70), (1301, 707))]
+filt = 0
 if len(sys.argv) > 1:
     a = [int(v) for v in sys.argv[1:5]]
     shapes = [((a[0], a[1]), (a[2], a[3]))]
+    filt = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 for (sw, sh), (dw, dh) in shapes:
     src = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
     dev = torch.from_numpy(src).cuda()
     dst = torch.zeros((dh, dw, 4), dtype=torch.uint8, device="cuda")
     _native.check(lib.mic_resize(ctx.handle, ctypes.c_void_p(dev.data_ptr()), sw, sh, ctypes.c_void_p(dst.data_ptr()),
-                                 dw, dh, 0, ctypes.c_void_p(ctx.stream_ptr())))
+                                 dw, dh, filt, ctypes.c_void_p(ctx.stream_ptr())))
     got = dst.cpu().numpy()
-    want = oracle.resize(src, (dw, dh), 0)
+    want = oracle.resize(src, (dw, dh), filt)
     bad = (got != want)
     print(f"{sw}x{sh} -> {dw}x{dh}: mismatching bytes {int(bad.sum())} of {bad.size}; per channel {bad.sum(axis=(0, 1)).tolist()}")
     if bad.any():

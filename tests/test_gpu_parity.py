@@ -131,7 +131,8 @@ def test_resize_random_shapes_vs_oracle(gpu):
               ((799, 601), (160, 121)), ((1201, 5), (300, 5)), ((3, 900), (3, 100)), ((2, 2), (97, 33)),
               ((1, 7), (50, 3)), ((4000, 16), (40, 16)), ((16, 4000), (17, 33)), ((257, 255), (255, 257)),
               ((19, 23), (640, 480)), ((1023, 767), (511, 383)),
-              ((2000, 1500), (256, 192)), ((1501, 1999), (101, 123)), ((3000, 40), (97, 40))]  # banded source planes
+              ((2000, 1500), (256, 192)), ((1501, 1999), (101, 123)), ((3000, 40), (97, 40)),  # deep shrinks: many chunks
+              ((59, 450), (114, 25)), ((450, 59), (25, 114)), ((64, 1000), (64, 48))]  # rings of 20-32 slots (found by the soak)
     for i, ((sw, sh), (dw, dh)) in enumerate(shapes):
         src = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
         if i % 3 == 1:    # binary alpha, like the reference's bundles
