@@ -175,9 +175,6 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const RsJob *__restrict
 // The k index of both operands is defined by the same (lane >> 4, byte) -> window position map, so
 // the result does not depend on the hardware's internal k order; C/D follow the documented
 // col = lane & 15, row = 4 (lane >> 4) + reg map.  Bit-exact with the two-pass kernels above.
-#ifndef MIC_RS_CHAINS
-#define MIC_RS_CHAINS 4
-#endif
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) v4i *gv4ptr;
@@ -222,73 +219,27 @@ __device__ __forceinline__ uint32_t clip8x4_signed(v4i v) {
 
 __device__ __forceinline__ v4i shr8(v4i v) { return v4i{v[0] >> 8, v[1] >> 8, v[2] >> 8, v[3] >> 8}; }
 
-// One 16 x 16 tile of all four channels through the digit chain -> per channel one word of clipped
-// bytes.  load(c, ch) returns the data operand (A) of channel c, 64-sample chunk ch; f = the first
-// chunk's tap digits (B); fbase = where the tile's fragments start (further chunks -- windows wider than
-// 64 samples: shrinks below ~1/3 -- are read from there).  SINGLE: one chunk, the four channels' chains
-// are written side by side so that each MFMA's latency is covered by the other channels' work.
-template <bool SINGLE, bool SIGNED, class Load>
-__device__ __forceinline__ void tile4(Load load, const v4i (&f)[3], gv4ptr fbase, int n_chunks, v4i bias,
-                                      uint32_t (&w)[4]) {
-    if (SINGLE) {
-#if MIC_RS_CHAINS == 4
-        // all four channels' chains side by side: each MFMA's result is needed three MFMAs later, so the
-        // dependent shifts need no s_nop padding (registers: 4 x (operand + accumulator))
-        v4i a[4], acc[4];
+// One 16 x 16 tile of all four channels through the digit chain -> per channel one word of clipped bytes.
+// load(c) returns the data operand (A) of channel c, f = the tile's tap digits (B).  The four channels' chains
+// are written side by side: each MFMA's result is needed three MFMAs later, so the dependent shifts need no
+// s_nop padding.  SIGNED: clip to signed bytes (the horizontal pass, see clip8x4_signed).
+template <bool SIGNED, class Load>
+__device__ __forceinline__ void tile4(Load load, const v4i (&f)[3], v4i bias, uint32_t (&w)[4]) {
+    v4i a[4], acc[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) a[c] = load(c, 0);
+    for (int c = 0; c < 4; ++c) a[c] = load(c);
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
+    for (int d = 0; d < 3; ++d) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[c], f[d], d == 0 ? bias : acc[c], 0, 0, 0);
-            if (d < 2) {
+        for (int c = 0; c < 4; ++c)
+            acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[c], f[d], d == 0 ? bias : acc[c], 0, 0, 0);
+        if (d < 2) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = shr8(acc[c]);
-            }
+            for (int c = 0; c < 4; ++c) acc[c] = shr8(acc[c]);
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) w[c] = SIGNED ? clip8x4_signed(acc[c]) : clip8x4(acc[c]);
-#else
-        // two channels at a time: 2 x (operand + accumulator) live instead of 4 x (this kernel's register
-        // budget is what sets its occupancy), still two independent chains to hide each other's latency
-#pragma unroll
-        for (int c0 = 0; c0 < 4; c0 += 2) {
-            const v4i a0 = load(c0, 0), a1 = load(c0 + 1, 0);
-            v4i x = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, f[0], bias, 0, 0, 0);
-            v4i y = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, f[0], bias, 0, 0, 0);
-            x = shr8(x);
-            y = shr8(y);
-            x = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, f[1], x, 0, 0, 0);
-            y = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, f[1], y, 0, 0, 0);
-            x = shr8(x);
-            y = shr8(y);
-            x = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, f[2], x, 0, 0, 0);
-            y = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, f[2], y, 0, 0, 0);
-            w[c0] = SIGNED ? clip8x4_signed(x) : clip8x4(x);
-            w[c0 + 1] = SIGNED ? clip8x4_signed(y) : clip8x4(y);
-        }
-#endif
-    } else {
-        v4i acc[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = bias;
-#pragma unroll 1
-        for (int d = 0; d < 3; ++d) {
-#pragma unroll 1
-            for (int ch = 0; ch < n_chunks; ++ch) {
-                const v4i e = fbase[(ch * 3 + d) * 64];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(load(c, ch), e, acc[c], 0, 0, 0);
-            }
-            if (d < 2) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[c] = shr8(acc[c]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) w[c] = SIGNED ? clip8x4_signed(acc[c]) : clip8x4(acc[c]);
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] = SIGNED ? clip8x4_signed(acc[c]) : clip8x4(acc[c]);
 }
 
 // ---- resident planar copy of an atlas ------------------------------------------------------------
@@ -378,9 +329,9 @@ __device__ __forceinline__ const MIC_GLOBAL T *at(uint64_t base, uint32_t byte_o
     return reinterpret_cast<const MIC_GLOBAL T *>(reinterpret_cast<const MIC_GLOBAL char *>(base) + byte_off);
 }
 
-// ONE_CHUNK: every tile of both axes has its taps inside one 64-sample window (any scale down to ~1/3: what the
-// host checks per layer) -- the instantiation without the chunk loops, their registers and their branches.
-template <bool ONE_CHUNK>
+// Every tile of both axes of a layer that comes here has its taps inside ONE 64-sample window (any scale down to
+// ~1/3: the host checks it per layer; deeper shrinks, single images and small calls take the tile kernel of
+// kernels_resample_tile.hip) -- no chunk loops, their registers or their branches.
 __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const RsMarch *__restrict__ jobs) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
     __shared__ float recip[256];            // unpremultiply factors 255/a: an LDS read per pixel
@@ -507,9 +458,8 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                 zmask &= ~(1u << slot);
                 // D[row = 4 lh + reg (band row)][col = l15 (x)]: 4 consecutive rows of one column
                 uint32_t w[4];
-                auto load = [&](int c, int ch) { return *reinterpret_cast<const v4i *>(a0 + c * plane_s + 64 * ch); };
-                if (ONE_CHUNK || hm[1] == 1) tile4<true, true>(load, hf, hfbase, 1, hbias, w);
-                else tile4<false, true>(load, hf, hfbase, hm[1], hbias, w);
+                auto load = [&](int c) { return *reinterpret_cast<const v4i *>(a0 + c * plane_s); };
+                tile4<true>(load, hf, hbias, w);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m + 16 * c) = w[c];
             }
@@ -536,11 +486,8 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                     const int base16 = (v_ws >> 4) + lh;
                     uint32_t w[4];
                     // A[m = l15 (x)][k = 16 lh + j (window row)]; D[row = 4 lh + reg (x)][col = l15 (output row)]
-                    auto load = [&](int c, int ch) {
-                        return *reinterpret_cast<const v4i *>(r0 + (((base16 + 4 * ch) & rmask) << 6) + 16 * c);
-                    };
-                    if (ONE_CHUNK || v_nch == 1) tile4<true, false>(load, vf, vfbase, 1, vbias, w);
-                    else tile4<false, false>(load, vf, vfbase, v_nch, vbias, w);
+                    auto load = [&](int c) { return *reinterpret_cast<const v4i *>(r0 + ((base16 & rmask) << 6) + 16 * c); };
+                    tile4<false>(load, vf, vbias, w);
                     // alpha bytes all 0 or 255 <=> low 7 bits of every byte equal its top bit
                     const uint32_t top = (w[3] >> 7) & 0x01010101u;
                     const bool soft = (w[3] & 0x7F7F7F7Fu) != (top << 7) - top;
@@ -560,35 +507,24 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
     }
 }
 
-// jobs_dev[0, n_fast): layers whose tiles all fit one 64-sample chunk per axis (the lean instantiation, lds_fast
-// bytes of LDS); the rest: the general one (lds_rest).
-hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, int n_fast, size_t lds_fast, size_t lds_rest,
-                                 hipStream_t stream) {
+hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, size_t lds_bytes, hipStream_t stream) {
     if (n_jobs <= 0) return hipSuccess;
-    // opt the kernels in for more than 64 KB of dynamic LDS, once per device of this process
+    // opt the kernel in for more than 64 KB of dynamic LDS, once per device of this process
     // (atomic flags: two threads racing here both set the same attribute, which is harmless)
     static std::atomic<bool> attr_set[64];
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_march_kernel<true>),
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_march_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsMarchMaxLds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_march_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsMarchMaxLds);
         if (e != hipSuccess) return e;
         if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
-    for (int first = 0; first < n_fast; first += 65535) {  // grid.y limit
-        const int n = std::min(65535, n_fast - first);
-        hipLaunchKernelGGL(resample_march_kernel<true>, dim3((unsigned)kRsUnitsPerEntry, (unsigned)n), dim3(256), lds_fast,
-                           stream, jobs_dev + first);
-    }
-    for (int first = n_fast; first < n_jobs; first += 65535) {
+    for (int first = 0; first < n_jobs; first += 65535) {  // grid.y limit
         const int n = std::min(65535, n_jobs - first);
-        hipLaunchKernelGGL(resample_march_kernel<false>, dim3((unsigned)kRsUnitsPerEntry, (unsigned)n), dim3(256), lds_rest,
-                           stream, jobs_dev + first);
+        hipLaunchKernelGGL(resample_march_kernel, dim3((unsigned)kRsUnitsPerEntry, (unsigned)n), dim3(256), lds_bytes, stream,
+                           jobs_dev + first);
     }
     return hipGetLastError();
 }

@@ -575,28 +575,34 @@ static int atlas_ensure_planar(const mic_atlas *A, const std::vector<int> &need,
 // ------------------------------------------------------------------------------------ resample planning
 namespace {
 
-// One layer that needs Image.resize.
+// One layer that needs Image.resize.  Three device paths: the marching MFMA kernel (layers of atlases, one 64-sample
+// chunk per tile, calls big enough to fill the chip), the tile MFMA kernel (single images, deep shrinks, small
+// calls), the two-pass VALU kernels (windows no LDS holds).
 struct ResizePlan {
     uint64_t src;
     int sw, sh, dw, dh;
     size_t tmp_off = 0;   // scratch offset of the horizontal pass output (two-pass fallback, both axes)
     size_t dst_off = 0;   // scratch offset of the final image (unused when dst_ptr is set)
     uint64_t dst_ptr = 0; // caller-provided destination (mic_resize)
-    // marching MFMA kernel (source band + ring of intermediate rows in LDS); march == false: two-pass fallback
-    bool march = false;
-    bool one_chunk = false;  // every tile of both axes has one 64-sample chunk: the lean kernel instantiation
+    // marching kernel (source band + ring of intermediate rows in LDS)
+    bool march_ok = false;   // the layer qualifies (one chunk per tile on both axes, ring and band fit LDS)
+    bool march = false;      // ... and the call routes it there
     int pitch_c = 0, ring16 = 0, pitch_r = 0;
-    uint64_t planar_src = 0;  // the source's planar premultiplied copy (atlas copy, or arena scratch for mic_resize)
+    // tile kernel (source planes + 8-bit intermediate in LDS); tx16 == 0: two-pass fallback
+    int tx16 = 0, ty16 = 0, t_pitch_c = 0, t_pitch_r = 0, rows16 = 0;
+    uint64_t planar_src = 0;  // the cutout in its atlas' planar premultiplied copy (0: none)
     int planar_pitch = 0;
+    int atlas = -1, entry = -1;  // where the source is a cutout of an atlas
 };
 
 struct PassTables {
-    std::vector<RsMarch> fused;
-    std::vector<std::shared_ptr<FragBuffer>> frag_refs;  // keeps the tables `fused` points into alive
+    std::vector<RsMarch> fused;   // marching kernel entries
+    std::vector<RsTile> tiles;    // tile kernel entries: whole-window ones first, banded ones after
+    int tiles_whole = 0;
+    size_t tiles_lds = 0;
+    std::vector<std::shared_ptr<FragBuffer>> frag_refs;  // keeps the tables the entries point into alive
     int fused_layers = 0;
-    std::vector<uint8_t> fused_fast;  // per entry of `fused` (until they are sorted): one-chunk layer
-    int fused_n_fast = 0;             // entries [0, fused_n_fast) run the one-chunk instantiation, the rest the general one
-    size_t lds_fast = 0, lds_rest = 0;
+    size_t lds_march = 0;
     std::vector<RsJob> h, v;
     int max_h_out_w = 0, max_h_rows = 0, max_v_out_w = 0, max_v_out_h = 0;
 };
@@ -617,15 +623,61 @@ int window_touched(const std::vector<int32_t> &meta, int tiles, int per) {
 
 int round16(int v) { return (v + 15) / 16 * 16; }
 
-// Size the marching kernel's LDS for one layer: the source band covers what the 4 x-tiles of a strip can
-// touch, the ring holds the 16-row slots between the first and the last tap row of any tile of 16 output
-// rows (a tile is emitted as soon as its last band is in).  Leaves march == false when that does not
-// fit (extreme shrinks: the two-pass kernels take those).
+// Over all workgroup tiles of `per` 16-sample tiles along one axis: the largest span of samples a tile needs
+// (its window start .. one past its last tap).
+int window_needed(const std::vector<int32_t> &meta, int tiles, int per) {
+    int needed = 0;
+    for (int t0 = 0; t0 < tiles; t0 += per) {
+        const int t1 = std::min(tiles, t0 + per);
+        needed = std::max(needed, meta[4 * (t1 - 1) + 3] - meta[4 * t0]);
+    }
+    return needed;
+}
+
+// Pick the workgroup tile of the tile kernel for one layer: the biggest of a short list whose source planes +
+// intermediate planes fit LDS, preferring sizes that let three workgroups share a CU.  Leaves tx16 == 0 when
+// nothing fits (extreme shrinks: the two-pass kernels take those).
+int choose_tile(mic_ctx *ctx, ResizePlan *p, int filter) {
+    FragEntry fh, fv;
+    if (int rc = get_frags(ctx, p->sw, p->dw, filter, &fh)) return rc;
+    if (int rc = get_frags(ctx, p->sh, p->dh, filter, &fv)) return rc;
+    static const int kTiles[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
+    p->tx16 = 0;
+    if ((int64_t)p->sw * p->sh < 4) return MIC_OK;  // the kernel's 16-byte loads need 4 pixels to clamp into
+    if ((int64_t)p->sw * p->sh >= ((int64_t)1 << 30)) return MIC_OK;  // its 32-bit pixel index steps past the end
+    // Whole window resident first (preferred LDS size, then anything that fits); only windows too tall for that
+    // (deep shrinks) get source planes that hold one band of rows at a time.  Those have few output tiles, so the
+    // banded candidates go from the smallest tile up (more workgroups), with enough row tiles per band to keep
+    // the four waves busy.
+    for (const bool banded : {false, true}) {
+        for (const size_t cap : {kRsTilePreferredLds, kRsTileMaxLds}) {
+            for (int ti = 0; ti < 5; ++ti) {
+                const auto &t = kTiles[banded ? 4 - ti : ti];
+                // Pitches cover what a tile needs, not what its 64-sample chunks touch: a read past the end of a
+                // row lands in the next row (or in the slack after the last one) and meets zero tap digits.
+                const int pitch_c = round16(window_needed(*fh.meta_host, fh.tiles, t[0]));
+                const int pitch_r = round16(window_needed(*fv.meta_host, fv.tiles, t[1]));
+                const int rows16 = banded ? std::min(pitch_r, std::max(16, 64 / t[0])) : pitch_r;
+                if (banded && rows16 == pitch_r) continue;  // same as the unbanded candidate
+                if (rs_tile_lds_bytes(rows16, pitch_c, t[0], pitch_r) <= cap) {
+                    p->tx16 = t[0]; p->ty16 = t[1]; p->t_pitch_c = pitch_c; p->t_pitch_r = pitch_r; p->rows16 = rows16;
+                    return MIC_OK;
+                }
+            }
+        }
+    }
+    return MIC_OK;
+}
+
+// Does the layer qualify for the marching kernel, and with what LDS: the source band covers what the 4 x-tiles of
+// a strip can touch, the ring holds the 16-row slots between the first and the last tap row of any tile of 16
+// output rows (a tile is emitted as soon as its last band is in).
 int choose_march(mic_ctx *ctx, ResizePlan *p, int filter) {
     FragEntry fh, fv;
     if (int rc = get_frags(ctx, p->sw, p->dw, filter, &fh)) return rc;
     if (int rc = get_frags(ctx, p->sh, p->dh, filter, &fv)) return rc;
-    p->march = false;
+    p->march_ok = false;
+    if (fh.max_chunks != 1 || fv.max_chunks != 1) return MIC_OK;  // the kernel has no chunk loops
     int pitch_c = round16(window_touched(*fh.meta_host, fh.tiles, 4));
     if ((pitch_c / 16) % 2 == 0) pitch_c += 16;  // an odd number of 16-byte units per row spreads the rows over the banks
     int slots = 1;
@@ -633,12 +685,25 @@ int choose_march(mic_ctx *ctx, ResizePlan *p, int filter) {
     for (int t = 0; t < fv.tiles; ++t) slots = std::max(slots, (vm[4 * t + 3] - 1) / 16 - vm[4 * t] / 16 + 1);
     int ring16 = 4;
     while (ring16 < slots) ring16 *= 2;
-    if (ring16 > 32) return MIC_OK;  // the kernel tracks empty ring slots in a 32-bit mask
     const int pitch_r = 64 * ring16 + 16;  // per column: ring16 slots x 4 channels x 16 rows, + 16 to spread the banks
     if (rs_march_lds_bytes(pitch_c, pitch_r) > kRsMarchMaxLds) return MIC_OK;
-    p->march = true; p->pitch_c = pitch_c; p->ring16 = ring16; p->pitch_r = pitch_r;
-    p->one_chunk = fh.max_chunks == 1 && fv.max_chunks == 1;
+    p->march_ok = true; p->pitch_c = pitch_c; p->ring16 = ring16; p->pitch_r = pitch_r;
     return MIC_OK;
+}
+
+// Work units the marching kernel would cut a layer into (strips of 4 x-tiles x segments of seg tiles)
+int march_units(const ResizePlan &p, int64_t unit_px, int *seg_tiles_out) {
+    const int tiles_x = (p.dw + 15) / 16, tiles_y = (p.dh + 15) / 16;
+    // segments of equal height: about unit_px / 64 rows per unit, counted on whichever side has more of them (a
+    // unit's time goes with the source bands it marches through as much as with the output tiles it emits)
+    const double rows_per_tile = 16.0 * std::max(1.0, (double)p.sh / p.dh);
+    const int64_t want = std::max<int64_t>(1, (int64_t)((double)unit_px / 64.0 / rows_per_tile + 0.5));
+    const int seg_cap = (int)std::min<int64_t>(want, kRsMaxSegTiles);
+    int segs = (tiles_y + seg_cap - 1) / seg_cap;
+    const int seg_tiles = (tiles_y + segs - 1) / segs;
+    segs = (tiles_y + seg_tiles - 1) / seg_tiles;
+    if (seg_tiles_out) *seg_tiles_out = seg_tiles;
+    return ((tiles_x + 3) / 4) * segs;
 }
 
 // Pixels one work unit of the marching kernel should produce: enough units to fill every CU several
@@ -674,26 +739,35 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             f.sw = p.sw; f.sh = p.sh; f.dw = p.dw; f.dh = p.dh;
             f.tiles_x = fh.tiles; f.tiles_y = fv.tiles;
             f.strips = (fh.tiles + 3) / 4;
-            // segments of equal height: about unit_px / 64 rows per unit, counted on whichever side has
-            // more of them (a unit's time goes with the source bands it marches through as much as with
-            // the output tiles it emits: a 2x shrink has twice the bands per output tile)
-            const double rows_per_tile = 16.0 * std::max(1.0, (double)p.sh / p.dh);
-            const int64_t want = std::max<int64_t>(1, (int64_t)((double)unit_px / 64.0 / rows_per_tile + 0.5));
-            const int seg_cap = (int)std::min<int64_t>(want, kRsMaxSegTiles);
-            f.segs = (fv.tiles + seg_cap - 1) / seg_cap;
-            f.seg_tiles = (fv.tiles + f.segs - 1) / f.segs;
-            f.segs = (fv.tiles + f.seg_tiles - 1) / f.seg_tiles;
+            const int n_units = march_units(p, unit_px, &f.seg_tiles);
+            f.segs = n_units / f.strips;
             f.pitch_c = p.pitch_c; f.ring16 = p.ring16; f.pitch_r = p.pitch_r;
-            const int n_units = f.strips * f.segs;
             f.n_entries = (n_units + kRsUnitsPerEntry - 1) / kRsUnitsPerEntry;
             f.xcd_rot = pt->fused_layers++ & 7;  // the XCD that gets a layer's short last run rotates
-            for (f.entry = 0; f.entry < f.n_entries; ++f.entry) {
-                pt->fused.push_back(f);
-                pt->fused_fast.push_back(p.one_chunk ? 1 : 0);
-            }
-            const size_t lds = rs_march_lds_bytes(f.pitch_c, f.pitch_r);
-            if (p.one_chunk) pt->lds_fast = std::max(pt->lds_fast, lds);
-            else pt->lds_rest = std::max(pt->lds_rest, lds);
+            for (f.entry = 0; f.entry < f.n_entries; ++f.entry) pt->fused.push_back(f);
+            pt->lds_march = std::max(pt->lds_march, rs_march_lds_bytes(f.pitch_c, f.pitch_r));
+            continue;
+        }
+        if (p.tx16 > 0) {
+            FragEntry fh, fv;
+            if (int rc = get_frags(ctx, p.sw, p.dw, filter, &fh)) return rc;
+            if (int rc = get_frags(ctx, p.sh, p.dh, filter, &fv)) return rc;
+            pt->frag_refs.push_back(fh.buf);
+            pt->frag_refs.push_back(fv.buf);
+            RsTile f{};
+            f.src = p.planar_src ? p.planar_src : p.src; f.dst = dst;
+            f.planar_pitch = p.planar_src ? p.planar_pitch : 0;
+            f.hmeta = fh.meta; f.hbias = fh.bias; f.hfrag = fh.frags;
+            f.vmeta = fv.meta; f.vbias = fv.bias; f.vfrag = fv.frags;
+            f.sw = p.sw; f.sh = p.sh; f.dw = p.dw; f.dh = p.dh;
+            f.tx16 = p.tx16; f.ty16 = p.ty16;
+            f.tiles_x = (fh.tiles + p.tx16 - 1) / p.tx16; f.tiles_y = (fv.tiles + p.ty16 - 1) / p.ty16;
+            f.pitch_c = p.t_pitch_c; f.pitch_r = p.t_pitch_r; f.rows16 = p.rows16;
+            const int n_tiles = f.tiles_x * f.tiles_y;
+            f.n_entries = (n_tiles + kRsTilesPerEntry - 1) / kRsTilesPerEntry;
+            f.xcd_rot = pt->fused_layers++ & 7;  // the XCD that gets a layer's short last band rotates
+            for (f.entry = 0; f.entry < f.n_entries; ++f.entry) pt->tiles.push_back(f);
+            pt->tiles_lds = std::max(pt->tiles_lds, rs_tile_lds_bytes(f.rows16, f.pitch_c, f.tx16, f.pitch_r));
             continue;
         }
         uint64_t v_src = p.src;
@@ -731,13 +805,9 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             pt->max_v_out_h = std::max(pt->max_v_out_h, p.dh);
         }
     }
-    // one-chunk layers first (the lean instantiation), the general ones after: at most two launches
-    std::vector<RsMarch> fast, rest;
-    for (size_t i = 0; i < pt->fused.size(); ++i) (pt->fused_fast[i] ? fast : rest).push_back(pt->fused[i]);
-    pt->fused_n_fast = (int)fast.size();
-    pt->fused = std::move(fast);
-    pt->fused.insert(pt->fused.end(), rest.begin(), rest.end());
-    pt->fused_fast.clear();
+    // tile kernel: whole-window entries first, banded ones after (two instantiations, launch_resample_tile)
+    auto whole = [](const RsTile &f) { return f.rows16 >= f.pitch_r; };
+    pt->tiles_whole = (int)(std::stable_partition(pt->tiles.begin(), pt->tiles.end(), whole) - pt->tiles.begin());
     return MIC_OK;
 }
 
@@ -761,7 +831,7 @@ struct mic_plan {
     void *scratch = nullptr;   // resampled layers (persistent plans own it; transient ones borrow ctx->arena)
     size_t scratch_bytes = 0;
     void *tables_dev = nullptr;  // persistent plans: jobs | layers | h passes | v passes
-    size_t off_layers = 0, off_f = 0, off_h = 0, off_v = 0, total = 0;
+    size_t off_layers = 0, off_f = 0, off_t = 0, off_h = 0, off_v = 0, total = 0;
     mic_stats stats{};
     // Persistent plans: the job table only depends on the output pointers, so the device copies for
     // the last few sets of outputs are kept (callers rotate over a handful of output sets); a run onto
@@ -781,7 +851,8 @@ struct mic_plan {
 static void plan_offsets(mic_plan *P) {
     P->off_layers = align_up(sizeof(Job) * P->jobs.size(), 64);
     P->off_f = align_up(P->off_layers + sizeof(Layer) * P->layers.size(), 64);
-    P->off_h = align_up(P->off_f + sizeof(RsMarch) * P->pt.fused.size(), 64);
+    P->off_t = align_up(P->off_f + sizeof(RsMarch) * P->pt.fused.size(), 64);
+    P->off_h = align_up(P->off_t + sizeof(RsTile) * P->pt.tiles.size(), 64);
     P->off_v = align_up(P->off_h + sizeof(RsJob) * P->pt.h.size(), 64);
     P->total = align_up(P->off_v + sizeof(RsJob) * P->pt.v.size(), 64);
 }
@@ -810,6 +881,7 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
     size_t scratch_need = kPixelAlign;  // leading guard band
     // per atlas: (entry, plan) of the cutouts this call runs through the marching resample kernel
     std::vector<std::vector<std::pair<int, size_t>>> planar_need((size_t)std::max(n_atlases, 1));
+    constexpr int64_t kMarchMinUnits = 512;  // two workgroups per CU
 
     for (int ji = 0; ji < n_jobs; ++ji) {
         const mic_job &J = jobs[ji];
@@ -867,9 +939,10 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                     ResizePlan rp{};
                     rp.src = reinterpret_cast<uint64_t>(A->blob) + E.offset;
                     rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
+                    rp.atlas = Pl.atlas; rp.entry = it->second;
                     if (int rc = choose_march(ctx, &rp, filter)) return rc;
-                    if (rp.march) planar_need[(size_t)Pl.atlas].push_back({it->second, plans.size()});
-                    if (!rp.march && rp.dw != rp.sw && rp.dh != rp.sh) {
+                    if (int rc = choose_tile(ctx, &rp, filter)) return rc;
+                    if (rp.tx16 == 0 && rp.dw != rp.sw && rp.dh != rp.sh) {  // the two-pass fallback's intermediate
                         rp.tmp_off = scratch_need;
                         scratch_need = align_up(scratch_need + (size_t)rp.dw * rp.sh * 4 + kGuard, kPixelAlign);
                     }
@@ -903,17 +976,41 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
     }
     for (const Pending &pd : pending)
         P->layers[pd.layer].src = reinterpret_cast<uint64_t>(scratch) + plans[pd.plan].dst_off;
-    for (int a = 0; a < n_atlases; ++a) {
-        if (planar_need[(size_t)a].empty()) continue;
-        const mic_atlas *A = atlases[a];
-        std::vector<int> entries;
-        for (const auto &ne : planar_need[(size_t)a]) entries.push_back(ne.first);
-        if (int rc = atlas_ensure_planar(A, entries, stream)) return rc;
-        for (const auto &ne : planar_need[(size_t)a]) {
-            plans[ne.second].planar_src = reinterpret_cast<uint64_t>(A->planar->dev) + A->planar_off[(size_t)ne.first];
-            plans[ne.second].planar_pitch = A->planar_pitch[(size_t)ne.first];
+    // Route the layers that qualify for the marching kernel: it wins once the call has enough work units to fill
+    // the chip (its units are long chains of dependent bands; a few of them are a serial tail) and pays for the
+    // cutouts' planar copies, which a persistent plan or a bundle's later calls amortise.  Everything else goes to
+    // the tile kernel (reading a planar copy where the atlas already has one) or the two-pass fallback.
+    {
+        int64_t px = 0;
+        for (const ResizePlan &rp : plans)
+            if (rp.march_ok) px += (int64_t)rp.dw * rp.dh;
+        const int64_t unit_px = march_unit_px(px);
+        int64_t units = 0;
+        for (const ResizePlan &rp : plans)
+            if (rp.march_ok) units += march_units(rp, unit_px, nullptr);
+        const bool use_march = units >= kMarchMinUnits;
+        for (size_t i = 0; i < plans.size(); ++i) {
+            ResizePlan &rp = plans[i];
+            rp.march = rp.march_ok && use_march;
+            if (rp.march) planar_need[(size_t)rp.atlas].push_back({rp.entry, i});
         }
-        P->pt.frag_refs.push_back(A->planar);  // the pass tables point into it
+    }
+    for (int a = 0; a < n_atlases; ++a) {
+        const mic_atlas *A = atlases[a];
+        if (!planar_need[(size_t)a].empty()) {
+            std::vector<int> entries;
+            for (const auto &ne : planar_need[(size_t)a]) entries.push_back(ne.first);
+            if (int rc = atlas_ensure_planar(A, entries, stream)) return rc;
+        }
+        if (!A->planar) continue;
+        bool used = false;
+        for (ResizePlan &rp : plans) {  // marching layers need the copy; tile-kernel layers take it where it exists
+            if (rp.atlas != a || !(rp.march || rp.tx16 > 0) || !A->planar_built[(size_t)rp.entry]) continue;
+            rp.planar_src = reinterpret_cast<uint64_t>(A->planar->dev) + A->planar_off[(size_t)rp.entry];
+            rp.planar_pitch = A->planar_pitch[(size_t)rp.entry];
+            used = true;
+        }
+        if (used) P->pt.frag_refs.push_back(A->planar);  // the pass tables point into it
     }
     if (int rc = plan_passes(ctx, plans, filter, scratch, &P->pt)) return rc;
     plan_offsets(P);
@@ -925,6 +1022,9 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
         if (!P->pt.fused.empty())
             HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_f, P->pt.fused.data(),
                               sizeof(RsMarch) * P->pt.fused.size(), hipMemcpyHostToDevice));
+        if (!P->pt.tiles.empty())
+            HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_t, P->pt.tiles.data(),
+                              sizeof(RsTile) * P->pt.tiles.size(), hipMemcpyHostToDevice));
         if (!P->pt.h.empty())
             HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_h, P->pt.h.data(),
                               sizeof(RsJob) * P->pt.h.size(), hipMemcpyHostToDevice));
@@ -1047,6 +1147,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
             upload_dst = slot->dev;
             if (!P->layers.empty()) memcpy(hp + P->off_layers, P->layers.data(), sizeof(Layer) * P->layers.size());
             if (!P->pt.fused.empty()) memcpy(hp + P->off_f, P->pt.fused.data(), sizeof(RsMarch) * P->pt.fused.size());
+            if (!P->pt.tiles.empty()) memcpy(hp + P->off_t, P->pt.tiles.data(), sizeof(RsTile) * P->pt.tiles.size());
             if (!P->pt.h.empty()) memcpy(hp + P->off_h, P->pt.h.data(), sizeof(RsJob) * P->pt.h.size());
             if (!P->pt.v.empty()) memcpy(hp + P->off_v, P->pt.v.data(), sizeof(RsJob) * P->pt.v.size());
         }
@@ -1066,7 +1167,9 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], stream));
     HIP_TRY(launch_resample_march(reinterpret_cast<const RsMarch *>(dp + P->off_f), (int)P->pt.fused.size(),
-                                   P->pt.fused_n_fast, P->pt.lds_fast, P->pt.lds_rest, stream));
+                                   P->pt.lds_march, stream));
+    HIP_TRY(launch_resample_tile(reinterpret_cast<const RsTile *>(dp + P->off_t), (int)P->pt.tiles.size(),
+                                  P->pt.tiles_whole, P->pt.tiles_lds, stream));
     HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + P->off_h), (int)P->pt.h.size(),
                               P->pt.max_h_out_w, P->pt.max_h_rows, stream));
     HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + P->off_v), (int)P->pt.v.size(),
@@ -1316,43 +1419,29 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
     rp.src = reinterpret_cast<uint64_t>(src_dev);
     rp.sw = src_w; rp.sh = src_h; rp.dw = dst_w; rp.dh = dst_h;
     rp.dst_ptr = reinterpret_cast<uint64_t>(dst_dev);
-    if (int rc = choose_march(ctx, &rp, filter)) return rc;
-    // arena: the source's planar premultiplied copy (marching kernel) or the horizontal pass' output (two-pass fallback)
+    // a single image: the tile kernel (it premultiplies and planarises the window while loading it; the marching
+    // kernel would first need a planar copy of the whole source, and one image rarely fills the chip with its units)
+    if (int rc = choose_tile(ctx, &rp, filter)) return rc;
     size_t need = 0;
-    if (rp.march) {
-        rp.planar_pitch = (src_w + 15) / 16 * 16;
-        need = (size_t)4 * src_h * rp.planar_pitch;
-    } else if (dst_w != src_w && dst_h != src_h) {
-        need = (size_t)dst_w * src_h * 4 + kGuard;
-    }
+    if (rp.tx16 == 0 && dst_w != src_w && dst_h != src_h) need = (size_t)dst_w * src_h * 4 + kGuard;
     if (int rc = ensure_arena(ctx, need)) return rc;
-    if (rp.march) rp.planar_src = reinterpret_cast<uint64_t>(ctx->arena);
     PassTables pt;
     std::vector<ResizePlan> plans{rp};
     if (int rc = plan_passes(ctx, plans, filter, ctx->arena, &pt)) return rc;
-    const size_t off_v = 64, off_p = 128, off_f = 192;
-    const size_t total = off_f + sizeof(RsMarch) * std::max<size_t>(1, pt.fused.size());
+    const size_t off_v = 64, off_t = 128;
+    const size_t total = off_t + sizeof(RsTile) * std::max<size_t>(1, pt.tiles.size());
     Slot *slot = nullptr;
     if (int rc = acquire_slot(ctx, total, &slot)) return rc;
     char *hp = static_cast<char *>(slot->host);
     if (!pt.h.empty()) memcpy(hp, pt.h.data(), sizeof(RsJob));
     if (!pt.v.empty()) memcpy(hp + off_v, pt.v.data(), sizeof(RsJob));
-    if (rp.march) {
-        PlanarJob pj{};
-        pj.src = rp.src; pj.dst = rp.planar_src;
-        pj.w = src_w; pj.h = src_h; pj.pitch = rp.planar_pitch;
-        memcpy(hp + off_p, &pj, sizeof pj);
-    }
-    if (!pt.fused.empty()) memcpy(hp + off_f, pt.fused.data(), sizeof(RsMarch) * pt.fused.size());
+    if (!pt.tiles.empty()) memcpy(hp + off_t, pt.tiles.data(), sizeof(RsTile) * pt.tiles.size());
     HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, total, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipEventRecord(slot->ev, stream));
     slot->pending = true;
     char *dp = static_cast<char *>(slot->dev);
-    if (rp.march)
-        HIP_TRY(launch_planarize(reinterpret_cast<const PlanarJob *>(dp + off_p), 1,
-                                 (int64_t)(rp.planar_pitch / 4) * src_h, stream));
-    HIP_TRY(launch_resample_march(reinterpret_cast<const RsMarch *>(dp + off_f), (int)pt.fused.size(),
-                                   pt.fused_n_fast, pt.lds_fast, pt.lds_rest, stream));
+    HIP_TRY(launch_resample_tile(reinterpret_cast<const RsTile *>(dp + off_t), (int)pt.tiles.size(), pt.tiles_whole,
+                                  pt.tiles_lds, stream));
     HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp), (int)pt.h.size(), pt.max_h_out_w,
                               pt.max_h_rows, stream));
     HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + off_v), (int)pt.v.size(), pt.max_v_out_w,

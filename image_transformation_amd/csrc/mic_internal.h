@@ -104,6 +104,39 @@ constexpr int kRsUnitsPerEntry = 32;
 #define MIC_RS_WAVES 5  // waves per SIMD the marching kernel's register budget is set for
 #endif
 
+// One layer resized by the tile kernel (kernels_resample_tile.hip: single images, deep shrinks, small calls): both axes in one launch, source planes and the 8-bit
+// intermediate in LDS.  Axis tables are the fragment form of resample_coeffs.h (AxisFrags); an axis
+// that keeps its size gets the identity table (one tap of weight 1.0: the pass Pillow skips).
+struct alignas(16) RsTile {
+    uint64_t src, dst;
+    uint64_t hmeta, hbias, hfrag;  // horizontal axis: [xtiles][4] int32, [16 xtiles] int32, fragments
+    uint64_t vmeta, vbias, vfrag;  // vertical axis
+    int32_t sw, sh, dw, dh;
+    int32_t tx16, ty16;            // workgroup tile in units of 16 output samples
+    int32_t tiles_x, tiles_y;
+    int32_t pitch_c, pitch_r;      // bytes per row of a source plane / per column of an intermediate plane
+    int32_t rows16;                // rows of a source plane (multiple of 16): the whole window of a tile, or
+                                   // one band of it when the window is too tall for LDS (deep shrinks)
+    // A layer with more than kRsTilesPerEntry tiles takes several table entries (grid.y); workgroup
+    // bx of entry e works on tile ((bx + xcd_rot) & 7) * 4 n_entries + 4 e + (bx >> 3): workgroups
+    // are dealt round-robin over the 8 XCDs, so each XCD gets a contiguous band of the layer's tiles
+    // and neighbouring tiles (which share their source halo) share an L2.
+    int32_t entry, n_entries, xcd_rot;
+    // > 0: `src` is the atlas' planar premultiplied copy of the cutout (four planes of sh rows, this many
+    // bytes per row); 0: `src` is interleaved RGBA and is premultiplied while it is loaded.
+    int32_t planar_pitch;
+    int32_t pad;
+};
+static_assert(sizeof(RsTile) == 128, "RsTile layout");
+inline size_t rs_tile_lds_bytes(int rows16, int pitch_c, int tx16, int pitch_r) {
+    return 4 * ((size_t)rows16 * pitch_c + (size_t)16 * tx16 * pitch_r) + 64;  // + slack for chunk over-reads
+}
+constexpr size_t kRsTilePreferredLds = 52 * 1024;  // three workgroups per CU (160 KB of LDS, 1 KB static each)
+constexpr size_t kRsTileMaxLds = 150 * 1024;       // last resort before the two-pass fallback
+// The launch is a (tiles per entry) x (entries) grid: a layer with more tiles takes several entries,
+// so that small layers do not pad the grid out to the largest layer's tile count.
+constexpr int kRsTilesPerEntry = 32;
+
 // ---- launchers (defined next to their kernels) -----------------------------------------------
 // The job table is sorted by kernel class; class_end[c] = one past the last job of class c for
 // c = 0 (aligned + solid opaque background), 1 (unaligned + solid), 2 (aligned + other background);
@@ -122,8 +155,8 @@ struct alignas(16) PlanarJob {
 };
 static_assert(sizeof(PlanarJob) == 32, "PlanarJob layout");
 hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream);
-hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, int n_fast, size_t lds_fast, size_t lds_rest,
-                                 hipStream_t stream);
+hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_resample_tile(const RsTile *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);
 // table_dev: scratch for max(W, H) <= 65535 colours (kGradientTableWords uint32)
 hipError_t launch_gradient(void *out, int W, int H, const uint8_t c1[3], const uint8_t c2[3], int vertical,
