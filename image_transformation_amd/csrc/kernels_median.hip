@@ -54,6 +54,10 @@ constexpr int kTicketOff = kGlobalCopies * kCopyWords;
 static_assert(kTicketOff < (int)kMedianScratchWords, "median scratch too small");
 static_assert(kHistWaves == 16, "median_select maps 3 channels x 256 bins onto 1024 threads");
 
+// Small grids (a bundle background is 15 blocks) keep one copy: the contention the copies relieve is not there,
+// and the last block would pay 8x the loads and 8x the re-zeroing for nothing.
+__device__ __host__ inline int median_copies(unsigned blocks) { return blocks > 32u ? kGlobalCopies : 1; }
+
 __device__ inline uint32_t agent_load(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -116,8 +120,10 @@ __device__ void median_select(const uint32_t *hist, uint32_t *out_rgba, uint32_t
     const int c = t >> 8, bin = t & 255;
     const bool act = c < 3;
     uint32_t n0 = 0, n1 = 0, v0 = 0, v1 = 0;
+    const int copies = median_copies(gridDim.x);
 #pragma unroll
-    for (int g = 0; g < kGlobalCopies; ++g) {  // 32 loads issued together: one round trip
+    for (int g = 0; g < kGlobalCopies; ++g) {  // up to 32 loads issued together: one round trip
+        if (g >= copies) break;
         const uint32_t *h = hist + g * kCopyWords;
         n0 += agent_load(h + kCountOff);
         n1 += agent_load(h + kCountOff + 1);
@@ -216,7 +222,7 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const uint32_t 
     }
     __syncthreads();
 
-    uint32_t *hist_copy = hist + (blockIdx.x & (kGlobalCopies - 1)) * kCopyWords;
+    uint32_t *hist_copy = hist + (blockIdx.x & (median_copies(gridDim.x) - 1)) * kCopyWords;
     for (int i = threadIdx.x; i < 2 * kSetWords; i += blockDim.x) {
         uint32_t s = 0;
 #pragma unroll
@@ -243,9 +249,11 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const uint32_t 
     if (!is_last) return;
     median_select(hist, out_rgba, wave_tot, res);
     __syncthreads();
-    // leave the scratch zeroed for the next call on this context
-    for (int i = threadIdx.x; i < (int)kMedianScratchWords; i += blockDim.x)
+    // leave the scratch zeroed for the next call on this context (the copies this launch used, and the ticket)
+    const int used = median_copies(gridDim.x) * kCopyWords;
+    for (int i = threadIdx.x; i < used; i += blockDim.x)
         __hip_atomic_store(hist + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_store(hist + kTicketOff, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // hist_dev must be zero on entry (mic_create clears it once; the kernel restores that state).
