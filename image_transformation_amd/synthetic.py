@@ -117,6 +117,26 @@ def placements_workload(W: int, H: int, n: int, seed: int, alpha_mode: str = "so
     return (W, H), objs, placements
 
 
+def placement_sets(objs: Dict[int, np.ndarray], W: int, H: int, seed: int, n_sets: int,
+                   scale_range: Tuple[float, float] = (0.5, 1.5)) -> List[List[dict]]:
+    """n_sets further placement lists over the same cutouts (placements_workload's draw, other seeds): a batch of
+    canvases whose layers all differ in scale, i.e. nothing for the resample dedup to share."""
+    out = []
+    for k in range(n_sets):
+        rng = np.random.default_rng(seed + 3000 + k)
+        placements = []
+        for oid, a in objs.items():
+            sh, sw = a.shape[:2]
+            s = float(rng.uniform(scale_range[0], scale_range[1]))
+            w = max(1, int(round(sw * s)))
+            h = max(1, int(round(sh * s)))
+            x1 = int(rng.integers(-w // 4, W - (3 * w) // 4 + 1))
+            y1 = int(rng.integers(-h // 4, H - (3 * h) // 4 + 1))
+            placements.append({"object_id": oid, "box": [x1, y1, x1 + w, y1 + h]})
+        out.append(placements)
+    return out
+
+
 RATIOS_C4 = ("9:16", "1:1", "16:9", "21:9")
 
 

@@ -28,13 +28,15 @@ constexpr int kIters = 2048;
         uint32_t a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, \
                  a6 = a0 + 6, a7 = a0 + 7;                                                          \
         uint32_t b = blockIdx.x | 0x01020304u, c = threadIdx.x * 3u + 0x3f800000u;                 \
+        const uint64_t m = __builtin_amdgcn_ballot_w64((threadIdx.x * 7u + blockIdx.x) & 4u);      \
         __syncthreads();                                                                            \
         const uint64_t t0 = __builtin_amdgcn_s_memtime();                                           \
         _Pragma("unroll 1") for (int i = 0; i < kIters; ++i) {                                      \
             asm volatile(ASM(0) ASM(1) ASM(2) ASM(3) ASM(4) ASM(5) ASM(6) ASM(7)                    \
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6),   \
                            "+v"(a7)                                                                 \
-                         : "v"(b), "v"(c));                                                         \
+                         : "v"(b), "v"(c), "s"(m)                                                   \
+                         : "vcc");                                                                  \
         }                                                                                           \
         const uint64_t t1 = __builtin_amdgcn_s_memtime();                                           \
         if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0; \
@@ -60,6 +62,32 @@ constexpr int kIters = 2048;
 #define OP_BFE(n) "v_bfe_u32 %" #n ", %" #n ", 8, 8\n"
 #define OP_CNDMASK(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
 
+#define OP_CNDMASK_S(n) "v_cndmask_b32_e64 %" #n ", %" #n ", %8, %10\n"
+#define OP_CMP_CNDMASK(n) "v_cmp_lt_u32_e32 vcc, %8, %" #n "\nv_cndmask_b32_e32 %" #n ", %" #n ", %9, vcc\n"
+#define OP_CMP_ONLY(n) "v_cmp_lt_u32_e32 vcc, %8, %" #n "\nv_add_u32 %" #n ", %" #n ", %9\n"
+#define OP_BFI(n) "v_bfi_b32 %" #n ", %8, %9, %" #n "\n"
+#define OP_ASHR(n) "v_ashrrev_i32 %" #n ", 31, %" #n "\n"
+#define OP_ASHR_BFI(n) "v_ashrrev_i32 %" #n ", 31, %" #n "\nv_bfi_b32 %" #n ", %" #n ", %9, %8\n"
+#define OP_MAX(n) "v_max_u32 %" #n ", %" #n ", %8\n"
+#define OP_AND_OR(n) "v_and_or_b32 %" #n ", %" #n ", %8, %9\n"
+#define OP_MUL24(n) "v_mul_u32_u24 %" #n ", %" #n ", %8\n"
+#define OP_SDWA(n) "v_add_u32_sdwa %" #n ", %" #n ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n"
+#define OP_MAD64(n) "v_mad_u64_u32 v[20:21], s[20:21], %" #n ", %8, v[22:23]\nv_xor_b32 %" #n ", %" #n ", v20\n"
+#define OP_MULLO(n) "v_mul_lo_u32 %" #n ", %" #n ", %8\n"
+#define OP_MADI24(n) "v_mad_i32_i24 %" #n ", %" #n ", %8, %9\n"
+#define OP_READLANE(n) "v_readlane_b32 s20, %" #n ", 3\nv_add_u32 %" #n ", %" #n ", %8\n"
+RATE_KERNEL(k_mullo, OP_MULLO)
+RATE_KERNEL(k_madi24, OP_MADI24)
+RATE_KERNEL(k_cndmask_s, OP_CNDMASK_S)
+RATE_KERNEL(k_cmp_cndmask, OP_CMP_CNDMASK)
+RATE_KERNEL(k_cmp_only, OP_CMP_ONLY)
+RATE_KERNEL(k_bfi, OP_BFI)
+RATE_KERNEL(k_ashr, OP_ASHR)
+RATE_KERNEL(k_ashr_bfi, OP_ASHR_BFI)
+RATE_KERNEL(k_max, OP_MAX)
+RATE_KERNEL(k_and_or, OP_AND_OR)
+RATE_KERNEL(k_mul24, OP_MUL24)
+RATE_KERNEL(k_sdwa, OP_SDWA)
 RATE_KERNEL(k_lshl_add, OP_LSHL_ADD)
 RATE_KERNEL(k_and, OP_AND)
 RATE_KERNEL(k_add, OP_ADD)
@@ -171,6 +199,18 @@ int main() {
     run_rate("v_xor_b32", k_xor, cyc_dev, sink_dev);
     run_rate("v_bfe_u32", k_bfe, cyc_dev, sink_dev);
     run_rate("v_cndmask_b32", k_cndmask, cyc_dev, sink_dev);
+    run_rate("v_cndmask_b32 sgpr", k_cndmask_s, cyc_dev, sink_dev);
+    run_rate("v_mul_lo_u32", k_mullo, cyc_dev, sink_dev);
+    run_rate("v_mad_i32_i24", k_madi24, cyc_dev, sink_dev);
+    run_rate("v_cmp+v_cndmask (x2)", k_cmp_cndmask, cyc_dev, sink_dev);
+    run_rate("v_cmp+v_add (x2)", k_cmp_only, cyc_dev, sink_dev);
+    run_rate("v_bfi_b32", k_bfi, cyc_dev, sink_dev);
+    run_rate("v_ashrrev_i32", k_ashr, cyc_dev, sink_dev);
+    run_rate("v_ashr+v_bfi (x2)", k_ashr_bfi, cyc_dev, sink_dev);
+    run_rate("v_max_u32", k_max, cyc_dev, sink_dev);
+    run_rate("v_and_or_b32", k_and_or, cyc_dev, sink_dev);
+    run_rate("v_mul_u32_u24", k_mul24, cyc_dev, sink_dev);
+    run_rate("v_add_u32 sdwa", k_sdwa, cyc_dev, sink_dev);
     run_rate("v_perm_b32", k_perm, cyc_dev, sink_dev);
     run_rate("v_ashr_pk_u8_i32", k_ashr_pk, cyc_dev, sink_dev);
     run_rate("v_cvt_pk_u8_f32", k_cvt_pk_u8, cyc_dev, sink_dev);
