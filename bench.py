@@ -492,6 +492,29 @@ def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_
             "resample_roofline": {"bound": "instruction issue (VALU + scalar), not hbm: profiles/r02_resample_experiments.txt",
                                   "algorithmic_bytes": rs_bytes, "achieved_GBps": round(rs_bytes / (r2 * 1e-3) / 1e9, 1),
                                   "frac_of_hbm_peak": frac(rs_bytes, r2)}}
+        if amode == "soft":
+            # the same in a BATCH (the headline's call shape): 16 canvases over the same cutouts, every canvas with its
+            # own scales and positions, so no resampled layer is shared -- one resample launch + one composite launch
+            nb = 16
+            sets = [ppl] + synthetic.placement_sets(pobjs, W, H, 3, nb - 1)
+            bplan = CompositeBatch(patlas, [SolidCanvas(psize, synthetic.SOLID_BG)] * nb,
+                                   [coerce_placements(patlas, q) for q in sets])
+            bout = bplan.alloc_outputs()
+            for _ in range(3):
+                bplan.run(bout)
+            torch.cuda.synchronize()
+            c3, r3 = bracketed(ctx, lambda k: bplan.run(bout, check=False), 10)
+            bs = bplan.stats()
+            out_px = sum(max(1, q["box"][2] - q["box"][0]) * max(1, q["box"][3] - q["box"][1]) for qs in sets for q in qs)
+            result["placements_mode_lanczos_batch"] = {
+                "alpha": amode, "canvases": nb, "resample_ms_per_canvas": round(r3 / nb, 4),
+                "composite_ms_per_canvas": round(c3 / nb, 4),
+                "Mpixels_per_s_kernels": round(nb * W * H / ((r3 + c3) * 1e-3) / 1e6, 1),
+                "composite_roofline_frac": frac(plan_bytes(bs), c3),
+                "resample_frac_of_hbm_peak": frac(4 * (bs["source_pixels"] + out_px), r3),
+                "note": "per-canvas times of ONE 16-canvas call; the single-canvas legs above are one generation of "
+                        "waves (8104 one-wave workgroups on 8192 slots) and so ramp-bound"}
+            del bplan, bout
         del pplan, patlas
 
     # ---- PCIe-inclusive step: job-table upload + composite + D2H of every canvas into pinned memory
