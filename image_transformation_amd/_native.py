@@ -47,7 +47,7 @@ class LabelStrip(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in
                 ("canvas_pixels", "layer_pixels", "source_pixels", "resampled_layers", "identity_layers",
-                 "skipped_placements", "composite_blocks")]
+                 "skipped_placements", "composite_blocks", "marched_layers")]
 
     def as_dict(self) -> Dict[str, int]:
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -45,7 +45,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *mic_last_error(void) { return g_err; }
-extern "C" int mic_version(void) { return (1 << 16) | 4; }  // 1.4: + mic_contact_sheet(_size); thread-safe contexts
+extern "C" int mic_version(void) { return (1 << 16) | 5; }  // 1.5: + mic_stats.marched_layers (1.4: + mic_contact_sheet(_size); thread-safe contexts)
 
 // ------------------------------------------------------------------------------------ blob layout
 namespace {
@@ -162,6 +162,9 @@ struct mic_ctx {
     std::deque<CoefKey> frag_order;      // insertion order, for eviction
     size_t frag_bytes = 0;
     size_t frag_cache_cap = kFragCacheBytes;  // MIC_FRAG_CACHE_MB at mic_create (tests shrink it)
+    // Work units a call's resampled layers must add up to before they take the marching kernel (two workgroups
+    // per CU); MIC_RS_MARCH_MIN_UNITS at mic_create (tests set 0 to run every qualifying layer through it).
+    int64_t march_min_units = 512;
     uint32_t *median_scratch = nullptr;  // device: histogram words + 1 result word
     uint32_t *gradient_table = nullptr;  // device: fill_gradient's per-position colours (allocated on first use)
     uint32_t *median_host = nullptr;     // pinned
@@ -221,6 +224,7 @@ extern "C" int mic_create(int device, mic_ctx **out) {
     ctx->device = device;
     if (const char *mb = getenv("MIC_FRAG_CACHE_MB"))
         if (atoi(mb) > 0) ctx->frag_cache_cap = (size_t)atoi(mb) << 20;
+    if (const char *mu = getenv("MIC_RS_MARCH_MIN_UNITS")) ctx->march_min_units = std::max<long long>(0, atoll(mu));
     for (auto &s : ctx->slots) {
         e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
         if (e != hipSuccess) {
@@ -881,7 +885,6 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
     size_t scratch_need = kPixelAlign;  // leading guard band
     // per atlas: (entry, plan) of the cutouts this call runs through the marching resample kernel
     std::vector<std::vector<std::pair<int, size_t>>> planar_need((size_t)std::max(n_atlases, 1));
-    constexpr int64_t kMarchMinUnits = 512;  // two workgroups per CU
 
     for (int ji = 0; ji < n_jobs; ++ji) {
         const mic_job &J = jobs[ji];
@@ -988,10 +991,11 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
         int64_t units = 0;
         for (const ResizePlan &rp : plans)
             if (rp.march_ok) units += march_units(rp, unit_px, nullptr);
-        const bool use_march = units >= kMarchMinUnits;
+        const bool use_march = units >= ctx->march_min_units;
         for (size_t i = 0; i < plans.size(); ++i) {
             ResizePlan &rp = plans[i];
             rp.march = rp.march_ok && use_march;
+            if (rp.march) ++P->stats.marched_layers;
             if (rp.march) planar_need[(size_t)rp.atlas].push_back({rp.entry, i});
         }
     }

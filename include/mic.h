@@ -231,6 +231,7 @@ typedef struct mic_stats {
     uint64_t identity_layers;
     uint64_t skipped_placements;  /* unknown ids                                           */
     uint64_t composite_blocks;    /* workgroups launched by the composite kernel           */
+    uint64_t marched_layers;      /* of resampled_layers: those run by the marching resample kernel (1.5) */
 } mic_stats;
 int mic_last_stats(const mic_ctx *ctx, mic_stats *out);
 int mic_plan_stats(const mic_plan *plan, mic_stats *out);

@@ -1,5 +1,7 @@
 """Randomised differential soak: HIP path vs the oracle on many random composites and resizes.
-Not part of the test suite (minutes); run on the GPU box:  python scripts/soak.py [seconds]"""
+Not part of the test suite (minutes); run on the GPU box:  python scripts/soak.py [seconds] [seed]
+With MIC_RS_MARCH_MIN_UNITS=0 in the environment every resampled layer that qualifies takes the marching kernel
+(by default only calls with >= 512 work units do; small calls take the tile kernel)."""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
@@ -71,5 +73,14 @@ while time.time() < t_end:
     if not np.array_equal(dst.cpu().numpy(), oracle.resize(src, (dw, dh), filt)):
         print("RESIZE MISMATCH", dict(seed=seed, src=(sw, sh), dst=(dw, dh), filt=filt))
         sys.exit(1)
+    # the same resize as the only layer of a composite onto a transparent canvas (the plan path: marching or tile
+    # kernel by the routing rule); alpha-over onto alpha 0 returns the layer wherever its alpha is > 0
+    a1 = Atlas({1: src})
+    got = composite_device(a1, [SolidCanvas((dw, dh), (0, 0, 0, 0))], [coerce_placements(a1, [{"object_id": 1, "box": [0, 0, dw, dh]}])],
+                           filter=filt)[0].cpu().numpy()
+    want = oracle.composite(np.zeros((dh, dw, 4), np.uint8), {1: src}, [{"object_id": 1, "box": [0, 0, dw, dh]}], filt)
+    if not np.array_equal(got, want):
+        print("PLAN RESIZE MISMATCH", dict(seed=seed, src=(sw, sh), dst=(dw, dh), filt=filt))
+        sys.exit(1)
     n_rs += 1
-print(f"soak ok: {n_comp} composites, {n_rs} resizes, seed {seed}, {budget:.0f} s")
+print(f"soak ok: {n_comp} composites, {n_rs} resizes, seed {seed}, {budget:.0f} s, MIC_RS_MARCH_MIN_UNITS={os.environ.get('MIC_RS_MARCH_MIN_UNITS')}")
