@@ -553,10 +553,11 @@ static int atlas_ensure_planar(const mic_atlas *A, const std::vector<int> &need,
         A->planar = std::move(buf);
     }
     std::vector<PlanarJob> jobs;
+    std::vector<int> building;  // marked built only once their kernel has been enqueued
     int64_t max_items = 0;
     for (int i : need) {
-        if (A->planar_built[(size_t)i]) continue;
-        A->planar_built[(size_t)i] = 1;
+        if (A->planar_built[(size_t)i] || std::find(building.begin(), building.end(), i) != building.end()) continue;
+        building.push_back(i);
         const BlobEntry &e = A->entries[(size_t)i];
         PlanarJob j{};
         j.src = reinterpret_cast<uint64_t>(A->blob) + e.offset;
@@ -573,6 +574,7 @@ static int atlas_ensure_planar(const mic_atlas *A, const std::vector<int> &need,
     HIP_TRY(hipEventRecord(slot->ev, stream));
     slot->pending = true;
     HIP_TRY(launch_planarize(static_cast<const PlanarJob *>(slot->dev), (int)jobs.size(), max_items, stream));
+    for (int i : building) A->planar_built[(size_t)i] = 1;
     return MIC_OK;
 }
 
