@@ -127,6 +127,25 @@ __global__ __launch_bounds__(1024) void k_mfma_i8(uint64_t *cycles, uint32_t *si
     sink[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s;
 }
 
+// the K = 32 form (gfx940's), 8 independent accumulators
+__global__ __launch_bounds__(1024) void k_mfma_i8_k32(uint64_t *cycles, uint32_t *sink) {
+    long a = (long)threadIdx.x * 0x0101010101010101l, b = (long)blockIdx.x + 0x0403020104030201l;
+    v4i acc[8];
+    for (int k = 0; k < 8; ++k) acc[k] = v4i{k, k, k, k};
+    __syncthreads();
+    const uint64_t t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int i = 0; i < kIters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = __builtin_amdgcn_mfma_i32_16x16x32_i8(a, b, acc[k], 0, 0, 0);
+    }
+    const uint64_t t1 = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+    int s = 0;
+    for (int k = 0; k < 8; ++k) s ^= acc[k][0] ^ acc[k][1] ^ acc[k][2] ^ acc[k][3];
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s;
+}
+
 // MFMA beside VALU in the same wave: 1 MFMA + V lshl_add per slot
 template <int V>
 __global__ __launch_bounds__(1024) void k_mfma_mix(uint64_t *cycles, uint32_t *sink) {
@@ -224,6 +243,7 @@ int main() {
     run_rate("v_med3_i32", k_med3, cyc_dev, sink_dev);
     run_rate("v_pk_add_u16", k_pk_add16, cyc_dev, sink_dev);
     run_rate("mfma_i32_16x16x64_i8", k_mfma_i8, cyc_dev, sink_dev);
+    run_rate("mfma_i32_16x16x32_i8", k_mfma_i8_k32, cyc_dev, sink_dev);
     run_rate("mfma + 2 valu", k_mfma_mix<2>, cyc_dev, sink_dev);
     run_rate("mfma + 4 valu", k_mfma_mix<4>, cyc_dev, sink_dev);
     run_rate("mfma + 8 valu", k_mfma_mix<8>, cyc_dev, sink_dev);
