@@ -193,8 +193,14 @@ static void run_rate(const char *name, rate_fn fn, uint64_t *cyc_dev, uint32_t *
         const int threads = 256 * wps, blocks = 256;
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(threads), 0, nullptr, cyc_dev, sink_dev);
         CHECK(hipDeviceSynchronize());
+        static hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        if (!ev0) { CHECK(hipEventCreate(&ev0)); CHECK(hipEventCreate(&ev1)); }
+        CHECK(hipEventRecord(ev0, nullptr));
         hipLaunchKernelGGL(fn, dim3(blocks), dim3(threads), 0, nullptr, cyc_dev, sink_dev);
+        CHECK(hipEventRecord(ev1, nullptr));
         CHECK(hipDeviceSynchronize());
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, ev0, ev1));
         std::vector<uint64_t> c((size_t)blocks * threads / 64);
         CHECK(hipMemcpy(c.data(), cyc_dev, c.size() * 8, hipMemcpyDeviceToHost));
         double sum = 0;
@@ -202,6 +208,7 @@ static void run_rate(const char *name, rate_fn fn, uint64_t *cyc_dev, uint32_t *
         const double per_wave = sum / c.size();  // s_memtime ticks of one wave's loop
         // per SIMD: wps waves each issued kIters * 8 instructions in that time
         printf("  wps%d: %6.2f tick/instr/SIMD", wps, per_wave / ((double)kIters * 8 * wps));
+        if (wps == 4) printf("  [loop %.0f ticks in a %.1f us launch]", per_wave, ms * 1e3);
     }
     printf("\n");
 }
