@@ -28,10 +28,37 @@ def hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm; set HIPCC=/path/to/hipcc)")
 
 
+DIGEST = LIB + ".digest"  # hex SHA-256 of what the library was built from (travels with the .so)
+
+
+def _flags() -> list:
+    return ["-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+            # MFMA accumulators in VGPRs: the resample kernel's epilogues read every accumulator with
+            # VALU instructions, which cannot address AGPRs (one v_accvgpr_read per value otherwise)
+            "-mllvm", "-amdgpu-mfma-vgpr-form"] + os.environ.get("MIC_EXTRA_CFLAGS", "").split()
+
+
+def _source_digest() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    h.update((ARCH + " " + " ".join(_flags())).encode())
+    for rel in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def _stale() -> bool:
+    """Is libmic.so missing or built from other sources / flags than the tree holds?  Decided by content (the digest
+    written next to the library), not by file times: a copy of the tree need not keep them in order."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
+    try:
+        with open(DIGEST, "r", encoding="ascii") as f:
+            return f.read().strip() != _source_digest()
+    except OSError:
+        pass
+    t = os.path.getmtime(LIB)  # a library from before the digest existed: file times
     deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
@@ -39,15 +66,28 @@ def _stale() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
-    cmd = [hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function",
-           # MFMA accumulators in VGPRs: the resample kernel's epilogues read every accumulator with
-           # VALU instructions, which cannot address AGPRs (one v_accvgpr_read per value otherwise)
-           "-mllvm", "-amdgpu-mfma-vgpr-form",
-           "-o", LIB] + os.environ.get("MIC_EXTRA_CFLAGS", "").split() + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    import fcntl
+    # one builder at a time (the ranks of a multi-GPU job import the package together); the others wait, find the
+    # library fresh and return.  The library is written under another name and renamed into place: a process that
+    # has the old one mapped keeps it, nobody ever sees a half-written file.
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():
+            return LIB
+        digest = _source_digest()
+        tmp = f"{LIB}.tmp.{os.getpid()}"
+        cmd = [hipcc(), f"--offload-arch={ARCH}"] + _flags() + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+        with open(DIGEST + ".tmp", "w", encoding="ascii") as f:
+            f.write(digest + "\n")
+        os.replace(DIGEST + ".tmp", DIGEST)
     return LIB
 
 

@@ -29,8 +29,16 @@ BILINEAR = 1
 def build(force: bool = False) -> str:
     """Compile libmic_oracle.so with gcc (seconds)."""
     src = os.path.join(_HERE, "mic_oracle.c")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libmic_oracle.so"])
+
+    def stale() -> bool:
+        return not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+
+    if force or stale():
+        import fcntl
+        with open(_LIB_PATH + ".lock", "w") as lock:  # the ranks of a multi-process test import this together
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            if force or stale():
+                subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libmic_oracle.so"])
     return _LIB_PATH
 
 

@@ -35,11 +35,26 @@ def test_header_symbols_exported_and_bound(built_lib):
     assert bound.mic_version() >> 16 == 1
 
 
-def test_struct_layouts_match_header():
+def test_struct_layouts_match_header(tmp_path):
+    """The ctypes mirrors against what a C compiler makes of include/mic.h itself (sizes and the offset of the last
+    field of every struct that crosses the ABI)."""
+    import subprocess
     from image_transformation_amd import _native
-    assert ctypes.sizeof(_native.Placement) == 24
-    assert ctypes.sizeof(_native.Job) == 40
-    assert ctypes.sizeof(_native.Stats) == 56
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mic.h"\n'
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mic_placement), offsetof(mic_placement, box), '
+                   'sizeof(mic_job), offsetof(mic_job, out_dev), sizeof(mic_stats), offsetof(mic_stats, marched_layers), '
+                   'sizeof(mic_label_strip), offsetof(mic_label_strip, coverage_host)); return 0; }\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)])
+    got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    mine = [ctypes.sizeof(_native.Placement), _native.Placement.box.offset,
+            ctypes.sizeof(_native.Job), _native.Job.out_dev.offset,
+            ctypes.sizeof(_native.Stats), _native.Stats.marched_layers.offset,
+            ctypes.sizeof(_native.LabelStrip), _native.LabelStrip.coverage_host.offset]
+    assert got == mine, (got, mine)
+    assert got[0] == 24 and got[2] == 40 and got[4] == 64
 
 
 def test_host_only_entry_points(built_lib):
