@@ -403,16 +403,23 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
     prefetch(band0);
 
     int yt = 0;           // next tile of output rows (relative to yt0) to emit ...
-    int v_ws = 0, v_nch = 1, v_frag = 0, v_hi = 0;  // ... and its table entry (window start, chunks, taps, window end)
-    auto next_tile = [&]() {
-        const v4i vm = yt < n_yt ? vm_lds[yt] : v4i{0, 1, 0, 0};
-        v_ws = __builtin_amdgcn_readfirstlane(vm[0]); v_nch = __builtin_amdgcn_readfirstlane(vm[1]);
-        v_frag = __builtin_amdgcn_readfirstlane(vm[2]); v_hi = __builtin_amdgcn_readfirstlane(vm[3]);
+    int v_ws = 0, v_hi = 0;  // ... and its window (first source row, one past the last)
+    // Its taps and bias wait in REGISTERS: they are fetched as soon as the tile before it has issued its last MFMA,
+    // ahead of that tile's epilogue and stores -- a tile's tap loads sit most of a tile (often a whole band) ahead of
+    // their use, and the in-order vmcnt wait for them does not cover the stores issued after them.  (One register
+    // set, reloaded in place: two alternating sets made hipcc merge the two copies of the tile code again and copy
+    // one set into the other behind a vmcnt(0).)
+    v4i vf[3];
+    int vb = 0;
+    auto fetch_taps = [&](int frag, int row0) __attribute__((always_inline)) {
+        vb = *at<int32_t>(J.vbias + (uint64_t)row0 * 4, l15x4);
+        gv4ptr vfbase = at<v4i>(J.vfrag + (uint64_t)frag * 3072, lane16);
+        vf[0] = vfbase[0]; vf[1] = vfbase[64]; vf[2] = vfbase[128];
     };
     {
         const v4i vm = vmeta[yt0];  // (the first entry straight from memory: vm_lds is not visible before the first barrier)
-        v_ws = __builtin_amdgcn_readfirstlane(vm[0]); v_nch = __builtin_amdgcn_readfirstlane(vm[1]);
-        v_frag = __builtin_amdgcn_readfirstlane(vm[2]); v_hi = __builtin_amdgcn_readfirstlane(vm[3]);
+        v_ws = __builtin_amdgcn_readfirstlane(vm[0]); v_hi = __builtin_amdgcn_readfirstlane(vm[3]);
+        fetch_taps(__builtin_amdgcn_readfirstlane(vm[2]), yt0 * 16);
     }
     uint32_t zmask = 0;   // bit s: ring slot s holds an all-zero band
     const uint32_t ring_bits = (uint32_t)((1ull << J.ring16) - 1ull);
@@ -467,6 +474,11 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
         // ---- tiles of output rows whose last tap row is now in the ring (the next tile's table entry waits in
         // scalar registers: a band that completes no tile costs one compare)
         while (yt < n_yt && v_hi <= 16 * (b + 1)) {
+            // the table entry of the tile after this one (the last tile re-reads its own: always a valid fetch)
+            const int t_n = min(yt + 1, n_yt - 1);
+            const v4i vm_n = vm_lds[t_n];
+            const int n_ws = __builtin_amdgcn_readfirstlane(vm_n[0]), n_frag = __builtin_amdgcn_readfirstlane(vm_n[2]);
+            const int n_hi = __builtin_amdgcn_readfirstlane(vm_n[3]);
             if (active) {
                 const int row0 = (yt0 + yt) * 16;  // first output row of the tile (scalar)
                 const bool inside = ox_ok && l15 < J.dh - row0;
@@ -479,19 +491,18 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                 const bool all_zero = (zmask & need) == need;
                 u32x4 px = {0u, 0u, 0u, 0u};
                 if (!all_zero) {
-                    const int vb = *at<int32_t>(J.vbias + (uint64_t)row0 * 4, l15x4);
-                    const v4i vbias = {vb, vb, vb, vb};
-                    gv4ptr vfbase = at<v4i>(J.vfrag + (uint64_t)v_frag * 3072, lane16);
-                    const v4i vf[3] = {vfbase[0], vfbase[64], vfbase[128]};
                     const int base16 = (v_ws >> 4) + lh;
                     uint32_t w[4];
                     // A[m = l15 (x)][k = 16 lh + j (window row)]; D[row = 4 lh + reg (x)][col = l15 (output row)]
                     auto load = [&](int c) { return *reinterpret_cast<const v4i *>(r0 + ((base16 & rmask) << 6) + 16 * c); };
-                    tile4<false>(load, vf, vbias, w);
+                    tile4<false>(load, vf, v4i{vb, vb, vb, vb}, w);
+                    fetch_taps(n_frag, (yt0 + t_n) * 16);
                     // alpha bytes all 0 or 255 <=> low 7 bits of every byte equal its top bit
                     const uint32_t top = (w[3] >> 7) & 0x01010101u;
                     const bool soft = (w[3] & 0x7F7F7F7Fu) != (top << 7) - top;
                     px = __any(soft) ? unpremultiply4(w, recip) : interleave4(w);
+                } else {
+                    fetch_taps(n_frag, (yt0 + t_n) * 16);
                 }
                 if (x_full) {  // (wave-uniform) one 16-byte store per lane
                     if (inside) *reinterpret_cast<MIC_GLOBAL u32x4_a4 *>(dst + o_idx) = px;
@@ -502,7 +513,7 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                 }
             }
             ++yt;
-            next_tile();
+            v_ws = n_ws; v_hi = n_hi;
         }
     }
 }
