@@ -173,22 +173,36 @@ def pack_blob(objects: Mapping[int, Any], pin: bool = False):
     nbytes = ctypes.c_size_t()
     _native.check(lib.mic_atlas_blob_size(n, _i32p(ws), _i32p(hs), ctypes.byref(nbytes)))
     torch = _torch()
-    # numpy, not torch.zeros: a torch CPU fill fans out over every core of the host (256 on the GPU
-    # boxes) and the thread wake-up alone cost ~40 ms per atlas
-    host_np = np.zeros(nbytes.value, np.uint8)
+    pinned = bool(pin) and torch.cuda.is_available()
+    if pinned:
+        # straight into a pinned buffer of the call's own (no second host copy before the upload); a pinned block
+        # comes back from the allocator with old contents, so the gaps between the images are cleared by hand
+        host = _pinned(nbytes.value)
+        host_np = host.numpy()
+    else:
+        # numpy, not torch.zeros: a torch CPU fill fans out over every core of the host (256 on the GPU
+        # boxes) and the thread wake-up alone cost ~40 ms per atlas
+        host_np = np.zeros(nbytes.value, np.uint8)
+        host = torch.from_numpy(host_np)
     offs = np.zeros(max(n, 1), np.uint64)
+    head = 32 + 32 * n
+    if pinned:
+        host_np[:min(head, nbytes.value)] = 0
     _native.check(lib.mic_atlas_blob_layout(n, _i32p(ids_a), _i32p(ws), _i32p(hs), _P(host_np.ctypes.data),
                                             nbytes.value, offs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))))
-    for a, off in zip(arrs, offs):
+    end = head  # one past the last byte written so far
+    for a, off, w, h in zip(arrs, offs, ws, hs):
+        off, size = int(off), int(w) * int(h) * 4
+        if pinned and off > end:
+            host_np[end:off] = 0
         if isinstance(a, Image.Image):
-            if not _pilmem.copy_to(a, host_np.ctypes.data + int(off)):
-                flat = np.asarray(a, dtype=np.uint8).reshape(-1)
-                host_np[int(off):int(off) + flat.size] = flat
+            if not _pilmem.copy_to(a, host_np.ctypes.data + off):
+                host_np[off:off + size] = np.asarray(a, dtype=np.uint8).reshape(-1)
         else:
-            host_np[int(off):int(off) + a.size] = a.reshape(-1)
-    host = torch.from_numpy(host_np)
-    if pin and torch.cuda.is_available():
-        host = host.pin_memory()
+            host_np[off:off + size] = a.reshape(-1)
+        end = max(end, off + size)
+    if pinned and nbytes.value > end:
+        host_np[end:] = 0
     return host
 
 
@@ -217,8 +231,11 @@ class Atlas(Mapping):
 
     def __init__(self, objects: Mapping[int, Any], device: Optional[int] = None):
         self.ctx = _native.context(device)
-        host = pack_blob(objects)
-        self._init_from_blob(_upload(host.numpy(), self.ctx), header=host.numpy())
+        host = pack_blob(objects, pin=True)  # packed straight into pinned memory: one host copy, then the DMA
+        torch = _torch()
+        blob = torch.empty(host.numel(), dtype=torch.uint8, device=self.ctx.torch_device)
+        blob.copy_(host, non_blocking=True)  # (torch's host allocator keeps `host` alive until the copy has run)
+        self._init_from_blob(blob, header=host.numpy()[:32 + 32 * len(objects)])
 
     def _init_from_blob(self, blob, header: Optional[np.ndarray] = None):
         self.blob = blob  # torch uint8 tensor on the device; owns the memory

@@ -366,3 +366,26 @@ def test_raw_abi_edges_hardened_in_round_2(abi):
     # destroy order: the atlas first, then the plan that was made from it
     assert lib.mic_atlas_destroy(atlas) == 0
     assert lib.mic_plan_destroy(plan) == 0
+
+
+def test_pack_blob_into_pinned_memory_is_byte_identical():
+    """Atlas() packs the cutouts straight into a pinned block, which the host allocator hands out with whatever a
+    previous user left in it: header, table, every gap between the 256-byte aligned images and the guard band at
+    the end must come out as zeros, exactly as in the pageable (np.zeros) form that rank 0 broadcasts."""
+    import torch
+    from PIL import Image
+    from image_transformation_amd.compositor import Atlas, pack_blob
+    rng = np.random.default_rng(12)
+    objs = {7: cases.synthetic.make_cutout(rng, 61, 45, "soft"), 3: cases.synthetic.make_cutout(rng, 33, 80, "binary"),
+            11: Image.fromarray(cases.synthetic.make_cutout(rng, 5, 3, "soft"), "RGBA"), 2: cases.synthetic.make_cutout(rng, 1, 1, "soft")}
+    want = pack_blob(objs)
+    assert not want.is_pinned()
+    for _ in range(3):
+        junk = torch.empty(want.numel(), dtype=torch.uint8, pin_memory=True)
+        junk.fill_(0xAB)
+        del junk  # back to the caching host allocator: the next block of this size is this one
+        got = pack_blob(objs, pin=True)
+        assert got.is_pinned() and torch.equal(got, want)
+    atlas = Atlas(objs)
+    assert torch.equal(atlas.blob.cpu(), want)
+    assert atlas[11].size == (5, 3) and len(atlas) == 4
