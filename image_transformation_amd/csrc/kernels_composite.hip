@@ -344,11 +344,10 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
 #pragma unroll
         for (int r = 0; r < kGroups; ++r) m[r] = __ballot(hit[r]);
         while ((m[0] | m[1] | m[2] | m[3]) != 0) {
-            // Straight-line on purpose (no per-group branches): groups without a pending layer
-            // replay a record that some other group hit and mask everything away, so that hipcc
-            // issues the four loads back to back and waits once.
-            const uint64_t m_any = m[0] | m[1] | m[2] | m[3];
-            const int i_any = __ffsll((long long)m_any) - 1;
+            // Groups without a pending layer this round are skipped by WAVE-UNIFORM branches (their masks come from
+            // ballots): no tap arithmetic, no load, no masking for them.  The loads of the groups that have one still
+            // issue back to back -- nothing between them waits on memory -- and the wave waits once, before the
+            // first consume.  (Per-LANE conditions around the loads are what made hipcc drain vmcnt between groups.)
             u32x4 s[kGroups];
             Layer L[kGroups];
             Tap tap[kGroups];
@@ -356,21 +355,25 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
 #pragma unroll
             for (int r = 0; r < kGroups; ++r) {  // issue: one 16-byte load per lane per group
                 const bool has = m[r] != 0;
-                // `i` comes from a ballot (wave-uniform): v_readlane broadcasts the record
-                const int i = has ? __ffsll((long long)m[r]) - 1 : i_any;
-                m[r] &= m[r] - 1;
-                L[r].src = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine.src >> 32), i) << 32) |
-                           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine.src, i);
-                L[r].dx = __builtin_amdgcn_readlane(mine.dx, i);
-                L[r].dy = __builtin_amdgcn_readlane(mine.dy, i);
-                L[r].w = __builtin_amdgcn_readlane(mine.w, i);
-                L[r].h = __builtin_amdgcn_readlane(mine.h, i);
                 has_layer[r] = has;
-                tap[r] = make_tap(L[r], G[r].x, G[r].y, has);
-                s[r] = load_tap(L[r], tap[r]);
+                s[r] = u32x4{0u, 0u, 0u, 0u};
+                if (has) {
+                    // `i` comes from a ballot (wave-uniform): v_readlane broadcasts the record
+                    const int i = __ffsll((long long)m[r]) - 1;
+                    m[r] &= m[r] - 1;
+                    L[r].src = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine.src >> 32), i) << 32) |
+                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine.src, i);
+                    L[r].dx = __builtin_amdgcn_readlane(mine.dx, i);
+                    L[r].dy = __builtin_amdgcn_readlane(mine.dy, i);
+                    L[r].w = __builtin_amdgcn_readlane(mine.w, i);
+                    L[r].h = __builtin_amdgcn_readlane(mine.h, i);
+                    tap[r] = make_tap(L[r], G[r].x, G[r].y, true);
+                    s[r] = load_tap(L[r], tap[r]);
+                }
             }
 #pragma unroll
             for (int r = 0; r < kGroups; ++r) {  // consume
+                if (!has_layer[r]) continue;
                 // the layer clipped at the canvas' right edge (only matters when groups can straddle)
                 const int wclip = ALIGNED ? L[r].w : min(L[r].w, W - L[r].dx);
                 s[r] = mask_tap(tap[r], s[r], 0, wclip);
@@ -378,7 +381,7 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
                     // a group that straddles a row end: its pixels W - x .. 3 continue at column 0 of
                     // the next row -- one more masked 16-byte load, only in waves that hold such a
                     // group.  Canvas column = x - W + j >= 0 <=> layer column >= -dx: clip on the left.
-                    const Tap t2 = make_tap(L[r], G[r].x - W, G[r].y + 1, has_layer[r] && G[r].k < kLaneNPx);
+                    const Tap t2 = make_tap(L[r], G[r].x - W, G[r].y + 1, G[r].k < kLaneNPx);
                     const int lo = max(0, -L[r].dx);
                     const u32x4 v2 = mask_tap(t2, load_tap(L[r], t2), lo, wclip - lo);
 #pragma unroll
