@@ -65,10 +65,25 @@ class _DecodeCache:
                 cls._bytes += nbytes
         return im.copy()
 
+    @classmethod
+    def size(cls, path) -> Tuple[int, int]:
+        p = os.fspath(path)
+        st = os.stat(p)
+        key = (os.path.abspath(p), st.st_mtime_ns, st.st_size)
+        with cls._lock:
+            im = cls._items.get(key)
+        return im.size if im is not None else cls.open_rgba(path).size
+
 
 def open_rgba(path) -> Image.Image:
     """Image.open(path).convert("RGBA") through the per-process decode cache."""
     return _DecodeCache.open_rgba(path)
+
+
+def rgba_size(path) -> Tuple[int, int]:
+    """Image.open(path).convert("RGBA").size: decodes the file (and fails on a broken one) like the reference does,
+    but only the first time a given version of the file is seen -- later calls read the decode cache."""
+    return _DecodeCache.size(path)
 
 
 def _image_to_array(img: Image.Image) -> np.ndarray:

@@ -11,7 +11,9 @@ both are div255(dst * (255 - m) + 128) per channel with alpha 255.
 from __future__ import annotations
 
 import ctypes
+import functools
 import json
+import threading
 from pathlib import Path
 from typing import List, Tuple
 
@@ -33,21 +35,34 @@ def thumbnail_size(size: Tuple[int, int], req: Tuple[int, int]) -> Tuple[int, in
     return ow.value, oh.value
 
 
+_fonts = threading.local()  # a FreeType face is not safe to share between threads: one font object per thread and size
+
+
 def _resolve_font(font_size: int):
-    """Same fallback chain as macro_placement_test.py:176-186."""
+    """Same fallback chain as macro_placement_test.py:176-186 (one font object per size and thread)."""
+    cache = _fonts.__dict__.setdefault("by_size", {})
+    if font_size in cache:
+        return cache[font_size]
+    font = None
     for name in ("DejaVuSans.ttf", "/usr/share/fonts/truetype/dejavu/DejaVuSans.ttf"):
         try:
-            return ImageFont.truetype(name, size=font_size)
+            font = ImageFont.truetype(name, size=font_size)
+            break
         except Exception:
             continue
-    try:
-        return ImageFont.load_default()
-    except Exception:
-        return None
+    if font is None:
+        try:
+            font = ImageFont.load_default()
+        except Exception:
+            font = None
+    cache[font_size] = font
+    return font
 
 
-def _label_strip(label: str, font, tx: int, ty: int):
-    """Coverage mask of draw.text((tx, ty), label) as (rgba strip, x, y) or None if no ink."""
+@functools.lru_cache(maxsize=512)
+def _label_mask(label: str, font):
+    """Coverage mask of draw.text((0, 0), label) cropped to its ink, with the crop's offset: (mask, dx, dy), or None
+    if the label leaves no ink.  Pure in (label, font object): a bundle's labels are rasterised once per process."""
     probe = ImageDraw.Draw(Image.new("L", (1, 1), 0))
     try:
         bbox = probe.textbbox((0, 0), label, font=font)
@@ -60,14 +75,28 @@ def _label_strip(label: str, font, tx: int, ty: int):
     box = mask_img.getbbox()
     if box is None:
         return None
-    m = np.asarray(mask_img.crop(box), np.uint8)
-    strip = np.zeros(m.shape + (4,), np.uint8)
-    strip[:, :, 3] = m
-    return strip, tx - _MARGIN + box[0], ty - _MARGIN + box[1]
+    m = np.ascontiguousarray(np.asarray(mask_img.crop(box), np.uint8))
+    m.setflags(write=False)
+    return m, box[0] - _MARGIN, box[1] - _MARGIN
+
+
+def _label_strip(label: str, font, tx: int, ty: int):
+    """Coverage mask of draw.text((tx, ty), label) as (mask, x, y) or None if no ink."""
+    got = _label_mask(label, font)
+    if got is None:
+        return None
+    m, dx, dy = got
+    return m, tx + dx, ty + dy
 
 
 def _measure_label(draw, label: str, font) -> Tuple[int, int]:
     """Text size with the reference's fallbacks (macro_placement_test.py:222-238)."""
+    return _measure_cached(label, font)
+
+
+@functools.lru_cache(maxsize=512)
+def _measure_cached(label: str, font) -> Tuple[int, int]:
+    draw = ImageDraw.Draw(Image.new("RGBA", (1, 1)))
     try:
         bbox = draw.textbbox((0, 0), label, font=font)
         return bbox[2] - bbox[0], bbox[3] - bbox[1]
@@ -121,8 +150,7 @@ def build_labeled_contact_sheet(objects_dir: str, results_json_path: str,
         strip = _label_strip(label, font, tx, ty)
         if strip is None:
             continue
-        arr, sx, sy = strip
-        mask = np.ascontiguousarray(arr[:, :, 3])
+        mask, sx, sy = strip
         keep.append(mask)
         st = strips[n_strips]
         st.cell, st.x, st.y, st.w, st.h = idx, int(sx), int(sy), int(mask.shape[1]), int(mask.shape[0])

@@ -22,7 +22,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 from PIL import Image
 
 from .background_resizing import solid_canvas
-from .compositor import SolidCanvas, coerce_placements, composite_device, load_object_images, _to_pil
+from .compositor import SolidCanvas, coerce_placements, composite_device, load_object_images, rgba_size, _to_pil
 from .contact_sheet import build_labeled_contact_sheet
 from .flex import layout_to_placements
 from .layout_constraints import compute_canvas_size
@@ -52,8 +52,7 @@ class _PngWriter:
 
 def read_original_size(bundle_dir: Path) -> Tuple[int, int]:
     """macro_placement_test.py:154-157."""
-    with Image.open(Path(bundle_dir) / "background.png") as im:
-        return im.convert("RGBA").size
+    return rgba_size(Path(bundle_dir) / "background.png")  # (decoded once per file version: the decode cache)
 
 
 def _iter_dirs(base: Path, idx: int) -> Dict[str, Path]:
