@@ -552,6 +552,30 @@ def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_
             "render_solidcanvas_to_pil_ms": round(t_render * 1e3, 3),
             "note": "composite(PIL bg, {id: PIL}, placements) -> PIL and render(layout, ObjectImages, SolidCanvas) -> PIL "
                     "at 3840x2160 / 32 objects, median wall time per call, cutouts resident (second call on)"}
+        # C1 (BASELINE configs[0], the reference's own CPU-runnable case): the committed squarespace bundle, 492 x 492,
+        # 4 cutouts -- the same call at the reference's own size, beside the same loop through Pillow on this host
+        try:
+            bdir = os.path.join(ROOT, "tests", "golden", "bundles", "squarespace")
+            with open(os.path.join(ROOT, "tests", "golden", "bundles.json"), encoding="utf-8") as f:
+                c1_row = next(r for r in json.load(f)["cases"] if r["name"] == "squarespace_1x1")
+            from image_transformation_amd.background_resizing import fill_solid
+            from image_transformation_amd.compositor import load_object_images
+            c1_objs = load_object_images(os.path.join(bdir, "results.json"))
+            c1_size = (492, 492)
+            c1_bg = fill_solid(os.path.join(bdir, "background.png"), c1_size)
+            c1_pl = flex.layout_to_placements(c1_row["layout"], c1_objs, c1_size)
+            c1_pl2 = [{"object_id": q["object_id"], "box": [q["box"][0], q["box"][1], q["box"][0] + int((q["box"][2] - q["box"][0]) * 1.2),
+                                                            q["box"][1] + int((q["box"][3] - q["box"][1]) * 1.2)]} for q in c1_pl]
+            c1_pil = {k: c1_objs[k] for k in c1_objs}
+            c1 = {}
+            for key, q in (("identity_scale", c1_pl), ("lanczos_x1.2", c1_pl2)):
+                t_mine, _ = _median_time(lambda: composite(c1_bg, c1_objs, q), 1.0, 300)
+                t_pil, _ = _median_time(lambda: _pillow_composite(c1_bg, c1_pil, q), 1.0, 300)
+                c1[key] = {"this_package_us": round(t_mine * 1e6, 1), "pillow_us": round(t_pil * 1e6, 1)}
+            c1["note"] = "composite(PIL bg, load_object_images(results.json), placements) -> PIL on the squarespace bundle, 492x492 / 4 objects, median wall time"
+            result["c1_bundle_dropin"] = c1
+        except (OSError, StopIteration, KeyError) as exc:
+            result["c1_bundle_dropin"] = {"skipped": repr(exc)}
     except ImportError:
         result["pil_dropin"] = None
 
