@@ -56,3 +56,38 @@ def test_concurrent_pil_composites_match_the_oracle():
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+def test_concurrent_contact_sheets_are_identical(golden_dir):
+    """Contact sheets built from several threads at once (each thread rasterises labels with a FreeType face of its
+    own; masks and measurements are cached per process) equal the sheet a single thread builds."""
+    import os
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need an MI355X; none is visible")
+    import cases
+    from image_transformation_amd.contact_sheet import build_labeled_contact_sheet
+    bundles = [os.path.join(cases.BUNDLE_DIR, b) for b in cases.BUNDLES]
+    want = [np.array(build_labeled_contact_sheet(os.path.join(b, "objects"), os.path.join(b, "results.json"))) for b in bundles]
+    errors = []
+    start = threading.Barrier(4)
+
+    def work(t):
+        try:
+            start.wait()
+            for k in range(6):
+                b = bundles[(t + k) % len(bundles)]
+                got = np.array(build_labeled_contact_sheet(os.path.join(b, "objects"), os.path.join(b, "results.json"),
+                                                          font_size=24))
+                if not np.array_equal(got, want[(t + k) % len(bundles)]):
+                    errors.append((t, k, "sheet differs"))
+                    return
+        except Exception as exc:  # noqa: BLE001
+            errors.append((t, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
