@@ -13,7 +13,7 @@ for alpha in os.environ.get("MIC_ALPHAS", "soft,binary").split(","):
     for _ in range(5):
         plan.run(out)
     torch.cuda.synchronize()
-    n = 30
+    n = int(os.environ.get("MIC_N", "30"))
     ctx.profile_begin(n)
     for _ in range(n):
         plan.run(out)
