@@ -21,8 +21,9 @@ from .compositor import SolidCanvas, _to_pil, _upload, open_rgba
 _P = ctypes.c_void_p
 
 
-def _load_background_rgba(background_path: str) -> Image.Image:
-    return open_rgba(background_path)
+def _load_background_rgba(background_path: str, shared: bool = False) -> Image.Image:
+    """(shared=True: a copy-on-write view of the decode cache, for the callers below that only read it)"""
+    return open_rgba(background_path, shared)
 
 
 def median_color_device(rgba_dev, ctx: Optional[_native.Context] = None) -> Tuple[int, int, int]:
@@ -47,7 +48,7 @@ def _median_color_nontransparent(img_rgba: Image.Image) -> Tuple[int, int, int]:
 def solid_canvas(background_path: str, canvas_size: Tuple[int, int]) -> SolidCanvas:
     """fill_solid() without materialising the pixels: the colour + size, which render() turns
     into an in-kernel solid background."""
-    color = _median_color_nontransparent(_load_background_rgba(background_path))
+    color = _median_color_nontransparent(_load_background_rgba(background_path, shared=True))
     return SolidCanvas(canvas_size, color + (255,))
 
 
@@ -108,7 +109,7 @@ def fill_gradient_device(canvas_size: Tuple[int, int], c1, c2, vertical: bool, d
 def fill_gradient(background_path: str, canvas_size: Tuple[int, int]) -> Image.Image:
     """Linear gradient background from edge medians (background_resizing.py:60-98): horizontal
     (left -> right) if the left/right medians are at most as far apart as top/bottom, else vertical."""
-    left, right, top, bottom = _edge_strip_median_colors(_load_background_rgba(background_path))
+    left, right, top, bottom = _edge_strip_median_colors(_load_background_rgba(background_path, shared=True))
     if _axis_variance(left, right) <= _axis_variance(top, bottom):
         return _to_pil(fill_gradient_device(canvas_size, left, right, vertical=False))
     return _to_pil(fill_gradient_device(canvas_size, top, bottom, vertical=True))

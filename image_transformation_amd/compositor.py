@@ -48,7 +48,7 @@ class _DecodeCache:
     LIMIT = 512 << 20
 
     @classmethod
-    def open_rgba(cls, path) -> Image.Image:
+    def open_rgba(cls, path, shared: bool = False) -> Image.Image:
         p = os.fspath(path)
         st = os.stat(p)  # raises FileNotFoundError like Image.open
         key = (os.path.abspath(p), st.st_mtime_ns, st.st_size)
@@ -63,6 +63,17 @@ class _DecodeCache:
                     cls._bytes = 0
                 cls._items[key] = im
                 cls._bytes += nbytes
+        if shared:
+            # a second Python object over the SAME pixel memory, flagged read-only: Pillow's in-place operations
+            # (putpixel, paste, alpha_composite, ImageDraw, putalpha ...) copy the pixels before they write, so the
+            # cache stays intact; only a write through load()'s pixel access raises.  For callers that never
+            # modify the cutouts (this package's own pipeline): no 0.5 MB copy per cutout and call.
+            try:
+                view = im._new(im.im)
+                view.readonly = 1
+                return view
+            except Exception:  # noqa: BLE001  (a Pillow without _new: the plain copy)
+                pass
         return im.copy()
 
     @classmethod
@@ -75,9 +86,9 @@ class _DecodeCache:
         return im.size if im is not None else cls.open_rgba(path).size
 
 
-def open_rgba(path) -> Image.Image:
-    """Image.open(path).convert("RGBA") through the per-process decode cache."""
-    return _DecodeCache.open_rgba(path)
+def open_rgba(path, shared: bool = False) -> Image.Image:
+    """Image.open(path).convert("RGBA") through the per-process decode cache (shared=True: see _DecodeCache)."""
+    return _DecodeCache.open_rgba(path, shared)
 
 
 def rgba_size(path) -> Tuple[int, int]:
@@ -388,9 +399,10 @@ def _as_atlas(objects, device: Optional[int] = None) -> Atlas:
     return Atlas(objects, device)
 
 
-def load_object_images(results_json_path: str) -> Dict[int, Image.Image]:
+def load_object_images(results_json_path: str, shared: bool = False) -> Dict[int, Image.Image]:
     """results.json -> {object_id: RGBA Image} (compositor.py:25-35).  PNG decode stays on the
-    host; the returned dict uploads itself to the GPU once, on first use."""
+    host; the returned dict uploads itself to the GPU once, on first use.  shared=True (this package's own
+    pipeline, which never modifies a cutout) hands out copy-on-write views of the decode cache instead of copies."""
     with open(results_json_path, "r", encoding="utf-8") as f:
         items = json.load(f)
     base = os.path.dirname(results_json_path)
@@ -398,7 +410,7 @@ def load_object_images(results_json_path: str) -> Dict[int, Image.Image]:
     keys = []
     for it in items:
         path = os.path.join(base, it["filename"])
-        out[int(it["object_id"])] = open_rgba(path)
+        out[int(it["object_id"])] = open_rgba(path, shared)
         st = os.stat(path)
         keys.append((int(it["object_id"]), os.path.abspath(path), st.st_mtime_ns, st.st_size))
     out._source_key = tuple(keys)  # (after the inserts above, which reset it)

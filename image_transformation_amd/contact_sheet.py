@@ -127,7 +127,7 @@ def build_labeled_contact_sheet(objects_dir: str, results_json_path: str,
     if not items:
         return SolidCanvas((cell_w, cell_h), (255, 255, 255, 255)).to_image()
 
-    objects = load_object_images(results_json_path)  # {id: image}; files missing -> FileNotFoundError like the reference
+    objects = load_object_images(results_json_path, shared=True)  # {id: image}; files missing -> FileNotFoundError like the reference
     atlas = objects.atlas()
     ids = [int(it["object_id"]) for it in items]
     labels = [str(it.get("label", f"id_{it['object_id']}")) for it in items]

@@ -102,7 +102,7 @@ def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, ori
     ow, oh = original_size
     sheet = build_labeled_contact_sheet(str(bundle / "objects"), str(results_json))
     canvas: SolidCanvas = solid_canvas(str(bg_path), canvas_size)
-    objects = load_object_images(str(results_json))  # resident atlas on first use
+    objects = load_object_images(str(results_json), shared=True)  # resident atlas on first use
     atlas = objects.atlas()
     with open(results_json, "r", encoding="utf-8") as f:
         id_to_label = {int(it["object_id"]): str(it.get("label", it["object_id"])) for it in json.load(f)}

@@ -166,3 +166,23 @@ def test_load_object_images_contents_and_error_order(tmp_path):
     rj.write_text(json.dumps(bad))
     with pytest.raises(KeyError):
         load_object_images(str(rj))
+
+
+def test_shared_views_of_the_decode_cache_are_copy_on_write(tmp_path):
+    """open_rgba(shared=True) / load_object_images(shared=True) (what this package's own pipeline uses) hand out a
+    second Image object over the cached pixels, flagged read-only: Pillow's in-place operations copy before they
+    write, so neither the cache nor another view ever sees a change."""
+    from PIL import Image, ImageDraw
+    from image_transformation_amd.compositor import open_rgba
+    p = tmp_path / "c.png"
+    Image.new("RGBA", (6, 5), (10, 20, 30, 40)).save(p)
+    a, b = open_rgba(p, shared=True), open_rgba(p, shared=True)
+    assert a is not b and a.readonly and a.tobytes() == b.tobytes()
+    a.putpixel((0, 0), (1, 1, 1, 1))
+    ImageDraw.Draw(b).rectangle([0, 0, 5, 4], fill=(9, 9, 9, 9))
+    c = open_rgba(p, shared=True)
+    c.alpha_composite(Image.new("RGBA", (6, 5), (0, 0, 0, 255)))
+    assert a.getpixel((0, 0)) == (1, 1, 1, 1) and a.getpixel((1, 0)) == (10, 20, 30, 40)
+    assert b.getpixel((3, 3)) == (9, 9, 9, 9) and c.getpixel((0, 0)) == (0, 0, 0, 255)
+    assert open_rgba(p).getpixel((0, 0)) == (10, 20, 30, 40)            # the plain call: a private copy, as before
+    assert open_rgba(p, shared=True).getpixel((3, 3)) == (10, 20, 30, 40)
