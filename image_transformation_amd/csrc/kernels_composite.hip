@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
     for (int base = 0; base < job.layer_count; base += 64) {
         // cull 64 layers at once: lane l holds record base + l
         Layer mine{};
-        bool hit[kGroups] = {};
+        bool hit[kGroups] = {false, false, false, false};
         // The runs' end points are recomputed here from the page origin (a few scalar adds) rather
         // than kept in 16 SGPRs across the rounds below: the unaligned instantiations were spilling
         // scalars.  The empty asm makes the origin opaque so that the recomputation is not hoisted.
@@ -343,11 +343,7 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
         uint64_t m[kGroups];
 #pragma unroll
         for (int r = 0; r < kGroups; ++r) m[r] = __ballot(hit[r]);
-        auto pending = [&]() { uint64_t a = 0;
-#pragma unroll
-            for (int r = 0; r < kGroups; ++r) a |= m[r];
-            return a; };
-        while (pending() != 0) {
+        while ((m[0] | m[1] | m[2] | m[3]) != 0) {
             // Groups without a pending layer this round are skipped by WAVE-UNIFORM branches (their masks come from
             // ballots): no tap arithmetic, no load, no masking for them.  The loads of the groups that have one still
             // issue back to back -- nothing between them waits on memory -- and the wave waits once, before the
@@ -425,13 +421,14 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
 #pragma unroll 1
                 for (int it = 0; it < kGroups * kLaneNPx; ++it) {
                     const uint32_t o = alpha_over(px[0][0], s[0][0]);
-#pragma unroll
-                    for (int g = 0; g < kGroups; ++g) {
-                        const uint32_t pin = g + 1 < kGroups ? px[(g + 1) % kGroups][0] : o;
-                        const uint32_t sin = g + 1 < kGroups ? s[(g + 1) % kGroups][0] : 0u;
-                        px[g] = u32x4{px[g][1], px[g][2], px[g][3], pin};
-                        s[g] = u32x4{s[g][1], s[g][2], s[g][3], sin};
-                    }
+                    px[0] = u32x4{px[0][1], px[0][2], px[0][3], px[1][0]};
+                    px[1] = u32x4{px[1][1], px[1][2], px[1][3], px[2][0]};
+                    px[2] = u32x4{px[2][1], px[2][2], px[2][3], px[3][0]};
+                    px[3] = u32x4{px[3][1], px[3][2], px[3][3], o};
+                    s[0] = u32x4{s[0][1], s[0][2], s[0][3], s[1][0]};
+                    s[1] = u32x4{s[1][1], s[1][2], s[1][3], s[2][0]};
+                    s[2] = u32x4{s[2][1], s[2][2], s[2][3], s[3][0]};
+                    s[3] = u32x4{s[3][1], s[3][2], s[3][3], 0u};
                 }
             }
         }
@@ -491,7 +488,7 @@ hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_
 // Image.new("RGBA", size, colour) (background_resizing.py:32): one 4 KiB page per workgroup.
 __global__ __launch_bounds__(256) void fill_kernel(uint32_t *__restrict__ out, uint32_t rgba,
                                                    int64_t n_px, int px_shift) {
-    const int64_t q0 = (int64_t)blockIdx.x * 1024 - px_shift + threadIdx.x * kLaneNPx;
+    const int64_t q0 = (int64_t)blockIdx.x * kPagePx - px_shift + threadIdx.x * kLaneNPx;
     gptr o = (gptr)out;
     if (q0 >= 0 && q0 + kLaneNPx <= n_px) {
         store4(o + q0, (u32x4)(rgba));
@@ -559,7 +556,7 @@ hipError_t launch_gradient(void *out, int W, int H, const uint8_t c1[3], const u
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream) {
     if (n_px == 0) return hipSuccess;
     const int px_shift = (int)((reinterpret_cast<uint64_t>(out) & 4095u) / 4);
-    const size_t pages = (n_px + px_shift + 1024 - 1) / 1024;
+    const size_t pages = (n_px + px_shift + kPagePx - 1) / kPagePx;
     hipLaunchKernelGGL(fill_kernel, dim3((unsigned)pages), dim3(256), 0, stream,
                        reinterpret_cast<uint32_t *>(out), rgba, (int64_t)n_px, px_shift);
     return hipGetLastError();

@@ -1102,7 +1102,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
                 return fail(MIC_ERR_INVALID, "job %d: output overlaps the background", ji);
             if (d.out % 4 != 0) return fail(MIC_ERR_INVALID, "job %d: canvas pointers must be 4-byte aligned", ji);
             // 4 KiB pages aligned to absolute address: one workgroup per page (see mic_internal.h)
-            d.px_shift = (int32_t)((d.out & (uint64_t)(kPagePx * 4 - 1)) / 4);
+            d.px_shift = (int32_t)((d.out & 4095u) / 4);
             d.n_pages = (int32_t)(((uint64_t)d.W * d.H + d.px_shift + kPagePx - 1) / kPagePx);
             max_pages = std::max(max_pages, d.n_pages);
         }

@@ -24,10 +24,7 @@ typedef const MIC_GLOBAL int32_t *gciptr;
 // (one division, layer culling, record broadcast) is amortised over 4 KiB.
 constexpr int kLaneNPx = 4;                    // adjacent pixels per lane per group (16 B)
 constexpr int kWavePx = 64 * kLaneNPx;         // 256 px = 1 KiB per wave-wide access
-#ifndef MIC_GROUPS
-#define MIC_GROUPS 4
-#endif
-constexpr int kGroups = MIC_GROUPS;            // groups per lane, 1 KiB apart
+constexpr int kGroups = 4;                     // groups per lane, 1 KiB apart
 constexpr int kPagePx = kWavePx * kGroups;     // 1024 px = 4 KiB per workgroup
 
 // One resolved placement: where the layer's pixels live and where they land on the canvas.
