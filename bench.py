@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- composited Mpixels/s at 4K canvas, 32 objects (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--workload c3|c4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` from a plain shell starts the N ranks itself (child processes through
+torch.distributed.run, before this process touches the GPU) and relays rank 0's JSON line.
 
 Workload (config.workload = "C3"): synthetic 3840x2160 canvas, 32 RGBA cutouts (binary alpha, as
 the reference's bundles), depth-2 row/column Flex-DSL layouts (seed 3).
@@ -25,7 +28,11 @@ cached either: every canvas of the batch has an atlas of its own and the sets ro
 
 N > 1: one process per GPU, variants sharded v -> GPU v mod N, the atlas is broadcast once over
 RCCL before the timed region, no collective on the data path ("scaling": "weak": B per GPU fixed).
-Rank 0 prints ONE JSON line.
+Rank 0 prints ONE JSON line; it names the backend, dist.get_world_size() and every rank's device.
+
+--workload c4 (and the `c4_strong` object inside every default line): BASELINE.json configs[3] exactly,
+a FIXED batch of 64 aspect-ratio variants of one 32-object bundle split v mod N, one launch of 64/N
+canvases per rank per step ("scaling": "strong"), atlas broadcast time reported separately.
 """
 from __future__ import annotations
 
@@ -52,6 +59,23 @@ def cpu_model() -> str:
     except OSError:
         pass
     return platform.processor() or platform.machine()
+
+
+def cpu_quota_cores():
+    """CPU time this process's cgroup may use, in cores (cpu.max / cfs quota), or None when unlimited.  A GPU box hands a
+    one-GPU job a share of the host (its 256 logical CPUs are visible, a fraction of them is usable)."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2
+            q, p = f.read().split()[:2]
+            return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+            q, p = int(f.read()), int(g.read())
+            return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_baseline(objs, placements, size, budget_s=12.0, max_reps=5000):
@@ -142,7 +166,12 @@ def cpu_baseline_threads(objs, placements, size, budget_s=8.0):
         n_thr = len(os.sched_getaffinity(0))
     except AttributeError:
         n_thr = os.cpu_count() or 1
-    n_thr = max(1, min(n_thr, 32))
+    # every CPU this process may use: its affinity mask, capped by the cgroup's CPU quota when there is one (threads
+    # beyond the quota are only throttled); each thread holds one 33 MB background and one 33 MB result at a time
+    affinity, quota = n_thr, cpu_quota_cores()
+    if quota is not None:
+        n_thr = min(n_thr, max(1, int(quota + 0.999)))
+    n_thr = max(1, min(n_thr, 512))
     done = [0] * n_thr
     t_end = time.perf_counter() + budget_s
 
@@ -163,7 +192,9 @@ def cpu_baseline_threads(objs, placements, size, budget_s=8.0):
         t.join()
     el = time.perf_counter() - t0
     return {"value": round(sum(done) * W * H / el / 1e6, 1), "unit": "Mpixels/s", "cores": n_thr, "kind": "port",
-            "sample": f"{sum(done)} whole-canvas composites over {n_thr} threads in {el:.1f} s, one image per thread"}
+            "nproc": os.cpu_count(), "affinity_cpus": affinity, "cgroup_cpu_quota_cores": quota,
+            "sample": f"{sum(done)} whole-canvas composites over {n_thr} threads (= every CPU this process may use: "
+                      f"affinity {affinity}, cgroup quota {quota}) in {el:.1f} s, one image per thread"}
 
 
 def bracketed(ctx, run, n):
@@ -204,16 +235,181 @@ def batch_leg(ctx, atlas, canvases, rows, n_sets_bytes=320 << 20, reps=30):
             "Mpixels_per_s": round(st["canvas_pixels"] / (c_ms * 1e-3) / 1e6, 1)}
 
 
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` from a plain shell: this process has not touched the GPU (no HIP call, no
+    torch.cuda.is_available()); it starts the N ranks as CHILD processes through torch.distributed.run (one rank
+    per GPU, rendezvous on 127.0.0.1), relays rank 0's single JSON line and returns the children's status.
+    Nothing is exec'ed over a process that has initialised the GPU."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, cwd=ROOT)
+    for line in proc.stdout:
+        # the one JSON line goes to stdout; the launcher's own chatter to stderr
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+class Dist:
+    """The N-rank protocol of the bench contract: barrier + synchronize on both sides of a timed region, MAX
+    (and MIN) over ranks.  world == 1: everything is local."""
+
+    def __init__(self, world, rank, dev, rehearsal):
+        self.world, self.rank, self.dev, self.rehearsal = world, rank, dev, rehearsal
+        self.backend = None
+        if world > 1:
+            import torch.distributed as dist
+
+            self.backend = dist.get_backend()
+
+    def barrier(self):
+        if self.world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+
+    def max_min(self, x: float):
+        if self.world == 1:
+            return x, x
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor([x, -x], dtype=torch.float64, device="cpu" if self.rehearsal else self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0].item()), -float(t[1].item())
+
+    def sum(self, x: float) -> float:
+        if self.world == 1:
+            return x
+        import torch
+        import torch.distributed as dist
+
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.rehearsal else self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t[0].item())
+
+    def gather(self, obj):
+        if self.world == 1:
+            return [obj]
+        import torch.distributed as dist
+
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
+
+def timed_steps(D: Dist, ctx, plan, out_sets, steps, warmup):
+    """W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize; the clock stops after this rank's
+    own synchronize (the closing barrier is not this rank's work).  -> (max over ranks s, min over ranks s,
+    event-bracketed kernel ms of this rank from a SEPARATE pass, n bracketed)"""
+    import torch
+
+    n_sets = len(out_sets)
+    for k in range(warmup):
+        plan.run(out_sets[k % n_sets])
+    torch.cuda.synchronize()
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        plan.run(out_sets[k % n_sets], check=False)
+    torch.cuda.synchronize()
+    elapsed_rank = time.perf_counter() - t0
+    D.barrier()
+    elapsed, elapsed_min = D.max_min(elapsed_rank)
+    n_br = max(10, min(steps, 50))
+    kernel_ms, _ = bracketed(ctx, lambda k: plan.run(out_sets[k % n_sets], check=False), n_br)
+    return elapsed, elapsed_min, kernel_ms, n_br
+
+
+def c4_strong_leg(D: Dist, args, steps, warmup):
+    """BASELINE.json configs[3] exactly: ONE 32-object bundle, a FIXED batch of 64 aspect-ratio variants (4 ratios x
+    16 Flex JSONs: canvases 2160x3840 / 2880x2880 / 3840x2160 / 4399x1885), variant v -> rank v mod G, one launch of
+    64/G canvases per rank per step.  Total work does not grow with G: "scaling": "strong".  The atlas is broadcast
+    once from rank 0 (RCCL) before the timed region and reported separately."""
+    import torch
+    from image_transformation_amd import flex, synthetic
+    from image_transformation_amd.batch import broadcast_atlas, shard_indices
+    from image_transformation_amd.compositor import CompositeBatch, SolidCanvas, coerce_placements
+
+    n_var = 64
+    objs, variants = synthetic.c4_workload(args.alpha, seed=4, n_variants=n_var)
+    torch.cuda.synchronize()
+    D.barrier()
+    t0 = time.perf_counter()
+    atlas = broadcast_atlas(objs if D.rank == 0 or D.world == 1 else None, src=0)
+    torch.cuda.synchronize()
+    bcast_first_ms = (time.perf_counter() - t0) * 1e3
+    D.barrier()
+    t0 = time.perf_counter()
+    atlas = broadcast_atlas(objs if D.rank == 0 or D.world == 1 else None, src=0)
+    torch.cuda.synchronize()
+    bcast_warm_ms = (time.perf_counter() - t0) * 1e3
+    ctx = atlas.ctx
+    mine = shard_indices(n_var, D.rank, D.world)
+    rows = [coerce_placements(atlas, flex.layout_to_placements(variants[v][1], atlas, variants[v][0])) for v in mine]
+    plan = CompositeBatch(atlas, [SolidCanvas(variants[v][0], synthetic.SOLID_BG) for v in mine], rows)
+    st = plan.stats()
+    set_bytes = 4 * st["canvas_pixels"]
+    n_sets = max(2, -(-(320 << 20) // max(set_bytes, 1)))  # outputs rotate over > 320 MB (here: 2 x 64/G canvases)
+    out_sets = [plan.alloc_outputs() for _ in range(n_sets)]
+    elapsed, elapsed_min, kernel_ms, n_br = timed_steps(D, ctx, plan, out_sets, steps, warmup)
+    px_total = D.sum(float(st["canvas_pixels"]))
+    canv_total = int(round(D.sum(float(len(mine)))))
+    k_max, k_min = D.max_min(kernel_ms)
+    b_alg = plan_bytes(st)
+    f_max, f_min = D.max_min(frac(b_alg, kernel_ms) or 0.0)
+    b_max, _ = D.max_min(bcast_warm_ms)
+    bf_max, _ = D.max_min(bcast_first_ms)
+    sizes = D.gather(sorted({tuple(variants[v][0]) for v in mine}))
+    del out_sets, plan
+    return {
+        "workload": "C4: one 32-object bundle, 64 aspect-ratio variants (9:16 / 1:1 / 16:9 / 21:9 x 16 Flex JSONs), "
+                    "variant v -> rank v mod G, one launch of 64/G canvases per rank per step",
+        "scaling": "strong", "value": round(px_total * steps / elapsed / 1e6, 1), "unit": "Mpixels/s",
+        "canvases_total": canv_total, "canvases_per_rank": len(mine), "steps": steps, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "per_rank": {"timed_region_s_max": round(elapsed, 6), "timed_region_s_min": round(elapsed_min, 6),
+                     "kernel_ms_max": round(k_max, 4), "kernel_ms_min": round(k_min, 4),
+                     "roofline_frac_max": round(f_max, 4), "roofline_frac_min": round(f_min, 4),
+                     "canvas_sizes": [[list(s) for s in ss] for ss in sizes]},
+        "roofline_rank0": {"kernel": "composite_kernel", "kernel_ms": round(kernel_ms, 4), "algorithmic_bytes_per_launch": b_alg,
+                           "frac": frac(b_alg, kernel_ms), "kernel_ms_source": f"{n_br} event-bracketed launches, separate pass"},
+        "atlas_broadcast": {"bytes": atlas.nbytes, "first_ms_max": round(bf_max, 3), "warm_ms_max": round(b_max, 3),
+                            "note": "one broadcast per BUNDLE from rank 0 (RCCL over xGMI when ranks > 1; a plain upload "
+                                    "at 1 rank), outside the timed region; first_ms includes context / communicator set-up"},
+    }, atlas
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=16, help="canvases per step per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="canvases per step per GPU (workload c3)")
+    ap.add_argument("--workload", default="c3", choices=["c3", "c4"],
+                    help="c3: weak scaling, --batch distinct 4K layouts per GPU (the headline); "
+                         "c4: strong scaling, BASELINE configs[3]'s fixed 64 variants split v mod G")
     ap.add_argument("--alpha", default="binary", choices=["binary", "soft", "opaque"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started from a plain shell: become the launcher (before anything touches the GPU)
+        raise SystemExit(self_launch(args.gpus))
 
     import numpy as np
     import torch
@@ -222,15 +418,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     # MIC_BENCH_REHEARSAL=1: all ranks share cuda:0 over gloo (to exercise the N>1 code path on a
     # one-GPU box); never set by the driver, whose ranks get one GPU each over RCCL.
     rehearsal = os.environ.get("MIC_BENCH_REHEARSAL") == "1"
     dev_index = 0 if rehearsal else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: no GPU {dev_index} on this node ({torch.cuda.device_count()} visible); "
+                         "MIC_BENCH_REHEARSAL=1 shares cuda:0 between the ranks")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
@@ -238,10 +434,39 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    D = Dist(world, rank, dev, rehearsal)
+    devices = D.gather({"rank": rank, "device_index": dev_index, "name": torch.cuda.get_device_name(dev_index),
+                        "pid": os.getpid()})
+    ranks_info = {"ranks": dist.get_world_size() if world > 1 else 1,
+                  "backend": (D.backend + (" (rehearsal: ranks share cuda:0)" if rehearsal else " (RCCL)" if D.backend == "nccl" else ""))
+                  if world > 1 else "none (single process)",
+                  "devices": devices}
 
     from image_transformation_amd import _native, flex, synthetic
     from image_transformation_amd.batch import broadcast_atlas, shard_indices
     from image_transformation_amd.compositor import Atlas, CompositeBatch, SolidCanvas, coerce_placements
+
+    if args.workload == "c4":
+        leg, _ = c4_strong_leg(D, args, args.steps, args.warmup)
+        result = {
+            "metric": "composited Mpixels/s at 4K canvas, 32 objects",
+            "value": leg["value"], "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": leg["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": leg["workload"], "canvases_per_step_total": leg["canvases_total"],
+                       "canvases_per_step_per_gpu": leg["canvases_per_rank"], "alpha": args.alpha,
+                       "parallelism": f"variants sharded v mod {world}", "background": "solid, synthesised in-kernel",
+                       "filter": "identity scale (Flex pipeline)"},
+            "roofline": {"bound": "hbm", "achieved": round((leg["roofline_rank0"]["frac"] or 0) * HBM_PEAK_GBS, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": leg["roofline_rank0"]["frac"], "traffic": None,
+                         **leg["roofline_rank0"]},
+            "per_rank": leg["per_rank"], "atlas": leg["atlas_broadcast"], "cpu_baseline": None, **ranks_info,
+        }
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     B = args.batch
     size, objs, layouts = synthetic.c3_workload(args.alpha, seed=3, n_layouts=B * world)
@@ -282,46 +507,16 @@ def main():
     n_sets = max(2, -(-(320 << 20) // set_bytes))
     out_sets = [plan.alloc_outputs() for _ in range(n_sets)]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for k in range(args.warmup):
-        plan.run(out_sets[k % n_sets])
-    torch.cuda.synchronize()
+    # ---- timed region: exactly K steps, nothing else; then a separate, event-bracketed pass of the same launches ----
+    elapsed, elapsed_min, kernel_ms, n_br = timed_steps(D, ctx, plan, out_sets, args.steps, args.warmup)
     stats = plan.stats()
+    kernel_ms_max, kernel_ms_min = D.max_min(kernel_ms)
 
-    # ---- timed region: exactly K steps, nothing else.  barrier + synchronize on both sides; the clock
-    # stops after this rank's own synchronize (the closing barrier is not this rank's work) ----
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        plan.run(out_sets[k % n_sets], check=False)
-    torch.cuda.synchronize()
-    elapsed_rank = time.perf_counter() - t0
-    barrier()
-    elapsed, elapsed_min = elapsed_rank, elapsed_rank
-    if world > 1:
-        t = torch.tensor([elapsed_rank, -elapsed_rank], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_min = float(t[0].item()), -float(t[1].item())
-
-    # ---- kernel duration: a separate, event-bracketed pass of the same launches ----
-    n_br = max(10, min(args.steps, 50))
-    kernel_ms, _ = bracketed(ctx, lambda k: plan.run(out_sets[k % n_sets], check=False), n_br)
-    if world > 1:
-        t = torch.tensor([kernel_ms, -kernel_ms], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        kernel_ms_max, kernel_ms_min = float(t[0].item()), -float(t[1].item())
-    else:
-        kernel_ms_max = kernel_ms_min = kernel_ms
-
-    # HBM bytes per launch from the PMC counters: measured separately with rocprofv3 (bench.py cannot
-    # run under --pmc and time itself) and committed under profiles/; only quoted for the workload
-    # it was measured on.
-    traffic, traffic_src = None, None
-    for name in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    # HBM bytes per launch from the PMC counters, and the kernel's average duration by rocprofv3's kernel trace:
+    # measured separately with rocprofv3 (bench.py cannot run under --pmc and time itself) and committed under
+    # profiles/; only quoted for the workload they were measured on.
+    traffic, traffic_src, rocprof_kernel_ms = None, None, None
+    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             with open(tpath) as f:
@@ -329,6 +524,8 @@ def main():
             if tj["workload"] == {"batch": B, "alpha": args.alpha, "canvas": [W, H], "objects": 32}:
                 traffic = tj["per_launch"]["hbm_bytes"]
                 traffic_src = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                if tj.get("kernel_trace"):
+                    rocprof_kernel_ms = round(tj["kernel_trace"]["average_ns"] * 1e-6, 4)
                 break
 
     px_per_step = B * W * H * world
@@ -354,7 +551,10 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "composite_kernel", "kernel_ms": round(kernel_ms, 4),
-                     "kernel_ms_source": f"{n_br} event-bracketed launches in a separate pass (not in the timed loop)",
+                     "kernel_ms_source": f"{n_br} event-bracketed launches in a separate pass (not in the timed loop); an event "
+                                         "pair between back-to-back launches adds ~2 us of idle GPU, so this bracket can exceed ms_per_step",
+                     "kernel_ms_rocprof": rocprof_kernel_ms,
+                     "frac_rocprof": frac(b_alg, rocprof_kernel_ms) if rocprof_kernel_ms else None,
                      "algorithmic_bytes_per_launch": b_alg,
                      "fabric": {"bytes": b_alg, "GBps": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
                                 "note": "algorithmic bytes / kernel time; the cutout reads (a third of the bytes) are "
@@ -369,10 +569,21 @@ def main():
         "host_layout_ms_per_image": {"python_mirror": round(layout_ms, 3),
                                      "native_mic_flex_place": round(native_ms, 4) if all(r is not None for r in native_rows) else None},
         "box_area_Mpixels_per_s": round(box_px * world * args.steps / elapsed / 1e6, 1),
+        **ranks_info,
     }
     if world > 1:
         result["per_rank"] = {"timed_region_s_max": round(elapsed, 6), "timed_region_s_min": round(elapsed_min, 6),
                               "kernel_ms_max": round(kernel_ms_max, 4), "kernel_ms_min": round(kernel_ms_min, 4)}
+
+    # ---- the strong-scaling leg (BASELINE configs[3]) rides in the same line at every N, so that the driver's
+    # N = 1, 2, 4, 8 runs carry both curves: `value` (weak, B canvases per GPU) and `c4_strong.value` (64 fixed)
+    if not args.no_extras or world > 1:
+        del out_sets[1:]  # (memory: the C4 leg allocates 2 x 64/G canvases of its own)
+        c4, c4_atlas = c4_strong_leg(D, args, max(5, min(args.steps, 50)), max(2, min(args.warmup, 10)))
+        result["c4_strong"] = c4
+        del c4_atlas
+        while len(out_sets) < n_sets:
+            out_sets.append(plan.alloc_outputs())
 
     if rank == 0 and world == 1 and not args.no_extras:
         extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_sets, n_sets, size, dev)
@@ -388,6 +599,188 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def _numpy_median_colour(img):
+    """This file's restatement of background_resizing.py:11-22 (per-channel np.median over alpha > 0, int())."""
+    import numpy as np
+
+    a = np.array(img)
+    mask = a[:, :, 3] > 0
+    px = a[:, :, :3][mask] if mask.any() else a[:, :, :3].reshape(-1, 3)
+    med = np.median(px, axis=0)
+    return tuple(int(v) for v in med)
+
+
+def _pillow_contact_sheet(results_json, thumb=(256, 256), cols=4, label_h=72, font_size=24):
+    """This file's restatement of the reference's labelled contact sheet (macro_placement_test.py:162-242): thumbnails by
+    Image.thumbnail(LANCZOS), centred on white cells, label text centred below (DejaVuSans when present)."""
+    from PIL import Image, ImageDraw, ImageFont
+
+    with open(results_json, encoding="utf-8") as f:
+        items = sorted(json.load(f), key=lambda it: int(it["object_id"]))
+    try:
+        font = ImageFont.truetype("DejaVuSans.ttf", size=font_size)
+    except OSError:
+        font = ImageFont.load_default()
+    base = os.path.dirname(results_json)
+    thumbs = []
+    for it in items:
+        im = Image.open(os.path.join(base, it["filename"])).convert("RGBA")
+        im.thumbnail(thumb, Image.LANCZOS)
+        thumbs.append((im, str(it.get("label", it["object_id"]))))
+    cw, chh = thumb[0], thumb[1] + label_h
+    rows = max(1, -(-len(thumbs) // cols))
+    sheet = Image.new("RGBA", (cols * cw if thumbs else cw, rows * chh), (255, 255, 255, 255))
+    draw = ImageDraw.Draw(sheet)
+    for i, (im, label) in enumerate(thumbs):
+        r, c = divmod(i, cols)
+        sheet.alpha_composite(im, dest=(c * cw + (cw - im.size[0]) // 2, r * chh + (thumb[1] - im.size[1]) // 2))
+        bb = draw.textbbox((0, 0), label, font=font)
+        tw, th = bb[2] - bb[0], bb[3] - bb[1]
+        draw.text((c * cw + (cw - tw) // 2, r * chh + thumb[1] + max(0, (label_h - th) // 2)), label, fill=(0, 0, 0, 255), font=font)
+    return sheet
+
+
+def _pillow_run_layouts(bundle, canvas_size, layouts, out_dir, flex):
+    """This file's restatement of the deterministic steps of run_macro_only (macro_placement_test.py:1414-1430,
+    1493-1513, 1679-1699) through Pillow / NumPy: contact sheet, fill_solid -> canvas.png, and per iteration: decode the
+    cutouts again, place, re-open canvas.png, composite, save the draft (out_dir None: nothing is written or re-opened)."""
+    from PIL import Image
+
+    rj = os.path.join(bundle, "results.json")
+    sheet = _pillow_contact_sheet(rj)
+    bg = Image.open(os.path.join(bundle, "background.png")).convert("RGBA")
+    canvas = Image.new("RGBA", canvas_size, _numpy_median_colour(bg) + (255,))
+    if out_dir:
+        sheet.save(os.path.join(out_dir, "contact_sheet.png"))
+        canvas.save(os.path.join(out_dir, "canvas.png"))
+    drafts = []
+    for i, layout in enumerate(layouts):
+        with open(rj, encoding="utf-8") as f:
+            objs = {int(it["object_id"]): Image.open(os.path.join(bundle, it["filename"])).convert("RGBA") for it in json.load(f)}
+        pl = flex.layout_to_placements(layout, objs, canvas_size)
+        cv = Image.open(os.path.join(out_dir, "canvas.png")).convert("RGBA") if out_dir else canvas
+        draft = _pillow_composite(cv, objs, pl)
+        if out_dir:
+            draft.save(os.path.join(out_dir, f"draft_macro_iter_{i:02d}.png"))
+        drafts.append(draft)
+    return drafts
+
+
+def pipeline_extras(result, ctx, dev):
+    """BASELINE configs[4] (C5: audio_book end to end at 7680x4320) stage by stage, the contact sheet, and the
+    deterministic harness (run_layouts) with and without its PNG artifacts -- wall ms of this package, kernel ms and
+    roofline fraction where one kernel dominates, and the same stage through Pillow / NumPy on this host."""
+    import tempfile
+
+    import numpy as np
+    import torch
+    from PIL import Image
+    from image_transformation_amd import flex
+    from image_transformation_amd.background_resizing import solid_canvas
+    from image_transformation_amd.compositor import (CompositeBatch, SolidCanvas, coerce_placements, load_object_images, render)
+    from image_transformation_amd.contact_sheet import build_labeled_contact_sheet
+    from image_transformation_amd.pipeline import run_layouts
+
+    gold = os.path.join(ROOT, "tests", "golden")
+    with open(os.path.join(gold, "big_hashes.json"), encoding="utf-8") as f:
+        big = {r["name"]: r for r in json.load(f)["cases"]}
+    with open(os.path.join(gold, "bundles.json"), encoding="utf-8") as f:
+        bundles = {r["name"]: r for r in json.load(f)["cases"]}
+
+    # ---------------- C5 ----------------
+    base = os.path.join(gold, "bundles", "audio_book")
+    rj, bgp = os.path.join(base, "results.json"), os.path.join(base, "background.png")
+    size = (7680, 4320)
+    W, H = size
+    sync = torch.cuda.synchronize
+    t_solid, _ = _median_time(lambda: solid_canvas(bgp, size), 1.0, 200)
+    canvas = solid_canvas(bgp, size)
+    bg_img = Image.open(bgp).convert("RGBA")
+    t_solid_cpu, _ = _median_time(lambda: _numpy_median_colour(bg_img), 1.0, 50)
+    assert _numpy_median_colour(bg_img) == tuple(canvas.rgba[:3])
+    t_sheet, _ = _median_time(lambda: build_labeled_contact_sheet(os.path.join(base, "objects"), rj), 1.0, 200)
+    t_sheet_cpu, _ = _median_time(lambda: _pillow_contact_sheet(rj), 1.0, 50)
+    objects = load_object_images(rj)
+    atlas = objects.atlas()
+    iters = []
+    pil_objs = {k: v for k, v in objects.items()}
+    bg8k = Image.new("RGBA", size, tuple(canvas.rgba))
+    for it in range(4):
+        pl = big[f"c5_audio_book_iter{it}"]["placements"]
+
+        def one():
+            out = render({"placements": pl}, objects, canvas, as_tensor=True)
+            sync()
+            return out
+        t_wall, _ = _median_time(one, 0.5, 50)
+        plan = CompositeBatch(atlas, [canvas], [coerce_placements(atlas, pl)])
+        outs = [plan.alloc_outputs() for _ in range(3)]  # 3 x 133 MB: beyond the Infinity Cache
+        for k in range(3):
+            plan.run(outs[k])
+        c_ms, r_ms = bracketed(ctx, lambda k: plan.run(outs[k % 3], check=False), 12)
+        st = plan.stats()
+        out_px = sum(max(1, q["box"][2] - q["box"][0]) * max(1, q["box"][3] - q["box"][1]) for q in pl)
+        rs_bytes = 4 * (st["source_pixels"] + out_px)
+        t0 = time.perf_counter()
+        _pillow_composite(bg8k, pil_objs, pl)
+        t_cpu = time.perf_counter() - t0
+        iters.append({"iteration": it, "render_to_device_wall_ms": round(t_wall * 1e3, 3), "resample_kernel_ms": round(r_ms, 4),
+                      "composite_kernel_ms": round(c_ms, 4), "composite_algorithmic_bytes": plan_bytes(st),
+                      "composite_roofline_frac": frac(plan_bytes(st), c_ms), "resample_algorithmic_bytes": rs_bytes,
+                      "resample_frac_of_hbm_peak": frac(rs_bytes, r_ms), "marched_layers": st["marched_layers"],
+                      "pillow_ms": round(t_cpu * 1e3, 1)})
+        del plan, outs
+    # PIL in -> PIL out (what the harness hands to .save()): includes the 133 MB download
+    t_pil, _ = _median_time(lambda: render({"placements": big["c5_audio_book_iter0"]["placements"]}, objects, canvas), 2.0, 20)
+    gpu_total = t_solid + t_sheet + sum(i["render_to_device_wall_ms"] for i in iters) * 1e-3
+    cpu_total = t_solid_cpu + t_sheet_cpu + sum(i["pillow_ms"] for i in iters) * 1e-3
+    result["c5_end_to_end"] = {
+        "what": "BASELINE configs[4]: audio_book bundle at 7680x4320 -- solid_canvas(background.png) (median colour), "
+                "labelled contact sheet, 4 composites (LANCZOS x8 upscales of the 3 cutouts; tests/golden/big_hashes.json)",
+        "solid_canvas_ms": round(t_solid * 1e3, 3), "solid_canvas_numpy_ms": round(t_solid_cpu * 1e3, 3),
+        "contact_sheet_ms": round(t_sheet * 1e3, 3), "contact_sheet_pillow_ms": round(t_sheet_cpu * 1e3, 3),
+        "composites": iters, "render_to_pil_wall_ms_iter0": round(t_pil * 1e3, 2),
+        "total_ms_device_resident": round(gpu_total * 1e3, 2), "total_ms_pillow_numpy": round(cpu_total * 1e3, 1),
+        "note": "wall ms are medians of warm calls (files in the decode cache, atlas resident); kernel ms from event-bracketed "
+                "launches of a persistent plan over 3 rotating 133 MB outputs; pillow_ms is ONE call per iteration"}
+
+    # ---------------- contact sheet at both bundle sizes ----------------
+    sq = os.path.join(gold, "bundles", "squarespace")
+    t_sq, _ = _median_time(lambda: build_labeled_contact_sheet(os.path.join(sq, "objects"), os.path.join(sq, "results.json")), 1.0, 200)
+    t_sq_cpu, _ = _median_time(lambda: _pillow_contact_sheet(os.path.join(sq, "results.json")), 1.0, 50)
+    result["contact_sheet"] = {"squarespace_ms": round(t_sq * 1e3, 3), "squarespace_pillow_ms": round(t_sq_cpu * 1e3, 3),
+                               "audio_book_ms": round(t_sheet * 1e3, 3), "audio_book_pillow_ms": round(t_sheet_cpu * 1e3, 3),
+                               "note": "PIL sheet returned, 1024x328; warm (decode cache, label masks, resident atlas)"}
+    result["contact_sheet_ms"] = round(t_sq * 1e3, 3)
+
+    # ---------------- run_layouts: the deterministic half of run_macro_only ----------------
+    lay = bundles["squarespace_1x1"]["layout"]
+    layouts = [lay] * 3
+    with tempfile.TemporaryDirectory() as td:
+        t_nosave, _ = _median_time(lambda: run_layouts(sq, "1:1", layouts, save=False), 1.0, 200)
+        t_save, _ = _median_time(lambda: run_layouts(sq, "1:1", layouts, output_root=td), 2.0, 100)
+        os.makedirs(os.path.join(td, "pil"), exist_ok=True)
+        t_cpu_nosave, _ = _median_time(lambda: _pillow_run_layouts(sq, (492, 492), layouts, None, flex), 1.0, 50)
+        t_cpu_save, _ = _median_time(lambda: _pillow_run_layouts(sq, (492, 492), layouts, os.path.join(td, "pil"), flex), 2.0, 50)
+        # a 4K draft through the package's PNG writer vs PIL's encoder (the artifact the harness saves per iteration)
+        from image_transformation_amd import png as mic_png
+        _, o4, l4 = __import__("image_transformation_amd.synthetic", fromlist=["c3_workload"]).c3_workload("binary", seed=3, n_layouts=1)
+        draft4k = render(l4[0], o4, SolidCanvas((3840, 2160), (38, 73, 115, 255)))
+        p_mine, p_pil = os.path.join(td, "d_mine.png"), os.path.join(td, "d_pil.png")
+        t_png, _ = _median_time(lambda: mic_png.save(draft4k, p_mine), 2.0, 50)
+        t_png_pil, _ = _median_time(lambda: draft4k.save(p_pil), 3.0, 5)
+        sizes = (os.path.getsize(p_mine), os.path.getsize(p_pil))
+    result["run_layouts"] = {
+        "what": "squarespace bundle, ratio 1:1 (492x492), 3 iterations: contact sheet + fill_solid + 3 x (place, clamp, composite)",
+        "ms_without_saving": round(t_nosave * 1e3, 3), "ms_with_png_artifacts": round(t_save * 1e3, 3),
+        "pillow_ms_without_saving": round(t_cpu_nosave * 1e3, 3), "pillow_ms_with_png_artifacts": round(t_cpu_save * 1e3, 3),
+        "png_4k_draft": {"libmic_writer_ms": round(t_png * 1e3, 2), "pil_save_ms": round(t_png_pil * 1e3, 1),
+                         "bytes_libmic": sizes[0], "bytes_pil": sizes[1]},
+        "note": "the Pillow figures restate the reference's sequence (cutouts decoded every iteration, canvas.png written and "
+                "re-opened) in this file; this package's artifacts: contact sheet, canvas, 3 drafts, 3 overlays, JSONs"}
+    result["run_layouts_ms"] = {"no_save": round(t_nosave * 1e3, 3), "save": round(t_save * 1e3, 3)}
 
 
 def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_sets, n_sets, size, dev):
@@ -578,6 +971,13 @@ def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_
             result["c1_bundle_dropin"] = {"skipped": repr(exc)}
     except ImportError:
         result["pil_dropin"] = None
+
+    # ---- BASELINE configs[4] (C5) stage by stage, the contact sheet and the deterministic harness, each beside the
+    # same stage through Pillow / NumPy on this host
+    try:
+        pipeline_extras(result, ctx, dev)
+    except ImportError as exc:  # no Pillow on this box
+        result["c5_end_to_end"] = result["contact_sheet"] = result["run_layouts"] = {"skipped": repr(exc)}
 
     # ---- background synthesis: median colour of RGBA images (noise: every bin populated)
     P = ctypes.c_void_p

@@ -99,6 +99,14 @@ SYMBOLS = {
     "mic_contact_sheet_size": (ctypes.c_int, [ctypes.c_int32] * 5 + [_I32P, _I32P]),
     "mic_contact_sheet": (ctypes.c_int, [_P, _P, ctypes.c_int32, _I32P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, _P, _P]),
+    "mic_png_bound": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
+    "mic_png_encode": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _P,
+                                      ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+    "mic_png_encode_rows": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_int, _P,
+                                           ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),
+    "mic_png_write": (ctypes.c_int, [ctypes.c_char_p, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, ctypes.c_int,
+                                     ctypes.c_int]),
+    "mic_png_write_rows": (ctypes.c_int, [ctypes.c_char_p, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_int]),
     "mic_last_stats": (ctypes.c_int, [_P, ctypes.POINTER(Stats)]),
     "mic_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
     "mic_profile_begin_sampled": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),

@@ -5,7 +5,12 @@
 // placements into device layer tables for the kernels.  No pixel arithmetic runs on the host.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/uio.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <cerrno>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -21,6 +26,7 @@
 #include "../../include/mic.h"  // declares mic_plan, mic_ctx, mic_atlas
 #include "mic_internal.h"
 #include "flex_place.h"
+#include "png_encode.h"
 #include "resample_coeffs.h"
 
 using namespace mic;
@@ -45,7 +51,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *mic_last_error(void) { return g_err; }
-extern "C" int mic_version(void) { return (1 << 16) | 5; }  // 1.5: + mic_stats.marched_layers (1.4: + mic_contact_sheet(_size); thread-safe contexts)
+extern "C" int mic_version(void) { return (1 << 16) | 6; }  // 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
 
 // ------------------------------------------------------------------------------------ blob layout
 namespace {
@@ -1545,6 +1551,97 @@ extern "C" int mic_draw_rect_outlines(mic_ctx *ctx, void *out_dev, int32_t width
     slot->pending = true;
     HIP_TRY(launch_rect_outlines(out_dev, width, height, static_cast<const OutlineRect *>(slot->dev), n, w, stream));
     return MIC_OK;
+}
+
+// ------------------------------------------------------------------------------------ PNG writer (host only)
+static int png_pieces(const void *const *rows, const void *base, int32_t w, int32_t h, size_t stride, int level, int threads,
+                      mic::PngPieces *pieces) {
+    if (w <= 0 || h <= 0 || w > kMaxDim || h > kMaxDim || (!rows && !base) || (!rows && stride < (size_t)w * 4))
+        return fail(MIC_ERR_INVALID, "mic_png: bad arguments");
+    std::vector<const uint8_t *> table;
+    if (!rows) {
+        table.resize((size_t)h);
+        for (int32_t y = 0; y < h; ++y) table[(size_t)y] = static_cast<const uint8_t *>(base) + (size_t)y * stride;
+    } else {
+        for (int32_t y = 0; y < h; ++y)
+            if (!rows[y]) return fail(MIC_ERR_INVALID, "mic_png: row %d is null", y);
+    }
+    std::string err;
+    const uint8_t *const *r = rows ? reinterpret_cast<const uint8_t *const *>(rows) : table.data();
+    if (int rc = mic::png_encode_rows(r, w, h, level, threads, pieces, &err))
+        return fail(rc == -3 ? MIC_ERR_NOMEM : MIC_ERR_INVALID, "%s", err.c_str());
+    return MIC_OK;
+}
+
+static int png_to_memory(const mic::PngPieces &pieces, void *out, size_t capacity, size_t *out_bytes) {
+    const size_t total = pieces.total();
+    if (out_bytes) *out_bytes = total;
+    if (!out || capacity < total) return fail(MIC_ERR_INVALID, "mic_png_encode: %zu bytes needed, capacity %zu", total, capacity);
+    uint8_t *o = static_cast<uint8_t *>(out);
+    for (const auto &p : pieces.pieces) {
+        memcpy(o, p.data, p.size);
+        o += p.size;
+    }
+    return MIC_OK;
+}
+
+static int png_to_file(const mic::PngPieces &pieces, const char *path) {
+    if (!path) return fail(MIC_ERR_INVALID, "mic_png_write: null path");
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+    if (fd < 0) return fail(MIC_ERR_INVALID, "mic_png_write: cannot open %s: %s", path, strerror(errno));
+    std::vector<iovec> iov;
+    for (const auto &p : pieces.pieces)
+        if (p.size) iov.push_back(iovec{const_cast<uint8_t *>(p.data), p.size});
+    size_t i = 0;
+    int rc = MIC_OK;
+    while (i < iov.size()) {
+        const ssize_t n = writev(fd, &iov[i], (int)std::min<size_t>(iov.size() - i, 64));
+        if (n < 0) {
+            if (errno == EINTR) continue;
+            rc = fail(MIC_ERR_INVALID, "mic_png_write: writing %s: %s", path, strerror(errno));
+            break;
+        }
+        size_t left = (size_t)n;
+        while (i < iov.size() && left >= iov[i].iov_len) left -= iov[i++].iov_len;
+        if (i < iov.size() && left) {
+            iov[i].iov_base = static_cast<char *>(iov[i].iov_base) + left;
+            iov[i].iov_len -= left;
+        }
+    }
+    if (close(fd) != 0 && rc == MIC_OK) rc = fail(MIC_ERR_INVALID, "mic_png_write: closing %s: %s", path, strerror(errno));
+    return rc;
+}
+
+extern "C" size_t mic_png_bound(int32_t width, int32_t height) { return mic::png_bound(width, height); }
+
+extern "C" int mic_png_encode(const void *rgba_host, int32_t width, int32_t height, size_t stride_bytes, int level,
+                              int threads, void *out, size_t capacity, size_t *out_bytes) {
+    mic::PngPieces pieces;
+    if (int rc = png_pieces(nullptr, rgba_host, width, height, stride_bytes, level, threads, &pieces)) return rc;
+    return png_to_memory(pieces, out, capacity, out_bytes);
+}
+
+extern "C" int mic_png_encode_rows(const void *const *rows_host, int32_t width, int32_t height, int level, int threads,
+                                   void *out, size_t capacity, size_t *out_bytes) {
+    if (!rows_host) return fail(MIC_ERR_INVALID, "mic_png_encode_rows: null row table");
+    mic::PngPieces pieces;
+    if (int rc = png_pieces(rows_host, nullptr, width, height, 0, level, threads, &pieces)) return rc;
+    return png_to_memory(pieces, out, capacity, out_bytes);
+}
+
+extern "C" int mic_png_write(const char *path, const void *rgba_host, int32_t width, int32_t height, size_t stride_bytes,
+                             int level, int threads) {
+    mic::PngPieces pieces;
+    if (int rc = png_pieces(nullptr, rgba_host, width, height, stride_bytes, level, threads, &pieces)) return rc;
+    return png_to_file(pieces, path);
+}
+
+extern "C" int mic_png_write_rows(const char *path, const void *const *rows_host, int32_t width, int32_t height, int level,
+                                  int threads) {
+    if (!rows_host) return fail(MIC_ERR_INVALID, "mic_png_write_rows: null row table");
+    mic::PngPieces pieces;
+    if (int rc = png_pieces(rows_host, nullptr, width, height, 0, level, threads, &pieces)) return rc;
+    return png_to_file(pieces, path);
 }
 
 extern "C" int mic_flex_place(const char *layout_json, size_t len, int n_objects, const int32_t *ids,

@@ -27,12 +27,14 @@ from .contact_sheet import build_labeled_contact_sheet
 from .flex import layout_to_placements
 from .layout_constraints import compute_canvas_size
 from .overlay import overlay_debug
+from . import png as mic_png
 
 
 class _PngWriter:
-    """PNG encoding is what is left of the wall time once the pixels come off the GPU (PIL's encoder,
-    ~10 ms per 492x492 artifact, 8 artifacts per run); PIL releases the GIL while it compresses, so the
-    files are written by a small thread pool while the next iteration is placed and composited."""
+    """The artifacts are written by libmic's own PNG writer (png.py / csrc/png_encode.cpp: Sub/Up filtering, LZ77 +
+    dynamic Huffman, no PIL encoder) on a small thread pool while the next iteration is placed and composited: the C
+    call releases the GIL.  PIL's zlib level 6 was ~10 ms per 492x492 artifact, 8 artifacts per run -- 95 % of the
+    deterministic loop.  Each file is encoded on ONE pool thread (threads=1); big images split themselves."""
 
     def __init__(self, workers: int = 8):
         from concurrent.futures import ThreadPoolExecutor
@@ -40,7 +42,8 @@ class _PngWriter:
         self._pending: List[Any] = []
 
     def save(self, image: Image.Image, path) -> None:
-        self._pending.append(self._pool.submit(image.save, path))
+        big = image.size[0] * image.size[1] >= (1 << 21)
+        self._pending.append(self._pool.submit(mic_png.save, image, path, mic_png.DEFAULT_LEVEL, 0 if big else 1))
 
     def close(self) -> None:
         try:

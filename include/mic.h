@@ -194,6 +194,24 @@ int mic_contact_sheet(mic_ctx *ctx, mic_atlas *atlas, int32_t n, const int32_t *
                       int32_t thumb_h, int32_t cols, int32_t label_h, int32_t n_strips,
                       const mic_label_strip *strips, void *out_dev, void *stream);
 
+/* ---- PNG writer: replaces PIL's encoder behind the reference's artifact saves ---------------------
+ * (`canvas_img.save(canvas_path)` macro_placement_test.py:1428-1430, `draft.save(...)` :1513 / :1699, the overlay
+ * :1514 / :1700).  Host-only (no context, no device): RGBA8 rows in host memory -> an 8-bit RGBA, non-interlaced
+ * PNG.  The bytes differ from Pillow's (other deflate), the decoded pixels are identical.  The image is cut into
+ * stripes that are filtered (Sub / Up per row), deflated (LZ77 + dynamic Huffman, stored where that is smaller)
+ * and CRC'd on `threads` worker threads (<= 0: one per ~384 KiB of pixels, at most min(cores, 16)); level 0 writes
+ * stored blocks only.  stride_bytes: distance between rows (>= width * 4).  The *_rows forms take one pointer per
+ * row (a PIL image keeps large images in several blocks).                                                     */
+size_t mic_png_bound(int32_t width, int32_t height);
+int mic_png_encode(const void *rgba_host, int32_t width, int32_t height, size_t stride_bytes, int level,
+                   int threads, void *out, size_t capacity, size_t *out_bytes);
+int mic_png_encode_rows(const void *const *rows_host, int32_t width, int32_t height, int level, int threads,
+                        void *out, size_t capacity, size_t *out_bytes);
+int mic_png_write(const char *path, const void *rgba_host, int32_t width, int32_t height, size_t stride_bytes,
+                  int level, int threads);
+int mic_png_write_rows(const char *path, const void *const *rows_host, int32_t width, int32_t height, int level,
+                       int threads);
+
 /* ---- layout: the integer half of render() -------------------------------------------------
  * Flex-DSL JSON text ({"root": {...}}) + cutout sizes + canvas size -> object ids and clamped boxes
  * in depth-first order: _measure_flex_node / _place_flex_container / _clamp_boxes_to_canvas

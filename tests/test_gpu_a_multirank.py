@@ -72,3 +72,48 @@ def test_bench_protocol_with_two_ranks():
     assert 0 < pr["timed_region_s_min"] <= pr["timed_region_s_max"]
     assert abs(rec["ms_per_step"] - pr["timed_region_s_max"] / 6 * 1e3) < 1e-3
     assert rec["roofline"]["frac"] > 0 and rec["cpu_baseline"] is None
+
+
+def _bench(args, env=None, timeout=600):
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env or dict(os.environ),
+                         capture_output=True, timeout=timeout, cwd=ROOT)
+    text = res.stdout.decode("utf-8", "replace")
+    assert res.returncode == 0, text + res.stderr.decode("utf-8", "replace")[-3000:]
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, text
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_c4_two_ranks():
+    """`python3 bench.py --gpus 2 --workload c4` from a plain shell (no torchrun in the command): the parent starts
+    the ranks itself before touching the GPU.  Strong scaling: the FIXED 64 C4 variants split v mod 2; the line says
+    how many ranks the process group really had, over which backend, on which devices."""
+    env = dict(os.environ, MIC_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    rec = _bench(["--gpus", "2", "--workload", "c4", "--steps", "6", "--warmup", "2"], env)
+    assert rec["ranks"] == 2 and rec["n_gpus"] == 2 and rec["scaling"] == "strong"
+    assert rec["backend"].startswith("gloo") and len(rec["devices"]) == 2
+    assert sorted(d["rank"] for d in rec["devices"]) == [0, 1] and all("MI355X" in d["name"] or d["name"] for d in rec["devices"])
+    assert len({d["pid"] for d in rec["devices"]}) == 2
+    assert rec["config"]["canvases_per_step_total"] == 64 and rec["config"]["canvases_per_step_per_gpu"] == 32
+    pr = rec["per_rank"]
+    assert 0 < pr["kernel_ms_min"] <= pr["kernel_ms_max"] and 0 < pr["timed_region_s_min"] <= pr["timed_region_s_max"]
+    # v mod 2: rank 0 renders the 9:16 and 16:9 canvases, rank 1 the 1:1 and 21:9 ones
+    assert pr["canvas_sizes"] == [[[2160, 3840], [3840, 2160]], [[2880, 2880], [4399, 1885]]]
+    assert rec["atlas"]["bytes"] > 15_000_000 and rec["atlas"]["warm_ms_max"] > 0
+    assert rec["value"] > 0 and abs(rec["ms_per_step"] - pr["timed_region_s_max"] / 6 * 1e3) < 1e-3
+
+
+def test_bench_c4_single_gpu_agrees_with_the_mixed_batch_leg():
+    """N = 1: `--workload c4` (64 canvases, wall clock) against the default line's `c4_strong` object (the same leg) and
+    its kernel-only `mixed_c4_batch` extra (16 canvases of the same four classes): one kernel, one answer."""
+    c4 = _bench(["--workload", "c4", "--steps", "20", "--warmup", "5"])
+    assert c4["ranks"] == 1 and c4["scaling"] == "strong" and c4["config"]["canvases_per_step_total"] == 64
+    full = _bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    assert full["scaling"] == "weak" and full["c4_strong"]["canvases_total"] == 64
+    assert abs(full["c4_strong"]["value"] / c4["value"] - 1) < 0.05, (full["c4_strong"]["value"], c4["value"])
+    mixed = full["mixed_c4_batch"]["Mpixels_per_s"]
+    assert abs(c4["value"] / mixed - 1) < 0.05, (c4["value"], mixed)
+    for key in ("c5_end_to_end", "contact_sheet", "run_layouts"):
+        assert key in full, key
