@@ -110,6 +110,28 @@ def copy_to(img: Image.Image, dst_addr: int) -> bool:
     return True
 
 
+def copy_from(img: Image.Image, src_addr: int) -> bool:
+    """memmove W*H*4 tightly packed bytes at src_addr INTO the image's own rows (an Image.new the caller owns).
+    False: the image's memory could not be located (the caller builds the image another way)."""
+    if getattr(img, "readonly", 0):
+        return False
+    runs = row_runs(img)
+    if runs is None:
+        return False
+    jobs = []
+    off = 0
+    for addr, n in runs:
+        for p in range(0, n, _PARALLEL_BYTES):
+            jobs.append((addr + p, src_addr + off + p, min(_PARALLEL_BYTES, n - p)))
+        off += n
+    if len(jobs) <= 1:
+        for d, s, n in jobs:
+            ctypes.memmove(d, s, n)
+    else:
+        list(_workers().map(lambda j: ctypes.memmove(*j), jobs))
+    return True
+
+
 def solid_colour(img: Image.Image) -> Optional[Tuple[int, int, int, int]]:
     """(r, g, b, a) if every pixel of the RGBA image has that value -- what background_resizing.fill_solid
     returns and run_macro_only re-opens from canvas.png every iteration (macro_placement_test.py:1510) --

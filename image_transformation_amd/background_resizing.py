@@ -36,6 +36,25 @@ def median_color_device(rgba_dev, ctx: Optional[_native.Context] = None) -> Tupl
     return int(out[0]), int(out[1]), int(out[2])
 
 
+def median_colors_device(views, ctx: Optional[_native.Context] = None):
+    """Median colours of several device uint8 (H, W, 4) tensors -- or strided VIEWS of one (rows a fixed pitch apart,
+    pixels adjacent: t[:, :8], t[-8:]) -- in ONE launch, one copy-back and one stream wait (mic_median_rgb_batch)."""
+    views = list(views)
+    if not views:
+        return []
+    ctx = ctx or _native.context(views[0].device.index)
+    arr = (_native.ImageView * len(views))()
+    for i, v in enumerate(views):
+        if v.dim() != 3 or v.shape[2] != 4 or v.stride(2) != 1 or v.stride(1) != 4 or v.numel() == 0:
+            raise ValueError("median views must be non-empty uint8 (H, W, 4) tensors whose pixels are adjacent")
+        arr[i].rgba_dev = v.data_ptr()
+        arr[i].width, arr[i].height = int(v.shape[1]), int(v.shape[0])
+        arr[i].stride_bytes = int(v.stride(0)) if v.shape[0] > 1 else 0
+    out = (ctypes.c_uint8 * (3 * len(views)))()
+    _native.check(_native.lib().mic_median_rgb_batch(ctx.handle, len(views), arr, out, _P(ctx.stream_ptr())))
+    return [(int(out[3 * i]), int(out[3 * i + 1]), int(out[3 * i + 2])) for i in range(len(views))]
+
+
 def _median_color_nontransparent(img_rgba: Image.Image) -> Tuple[int, int, int]:
     ctx = _native.context()
     if img_rgba.mode != "RGBA":
@@ -78,14 +97,15 @@ def fill_solid(background_path: str, canvas_size: Tuple[int, int]) -> Image.Imag
 
 def _edge_strip_median_colors(img: Image.Image, strip_px: int = 8):
     """(left, right, top, bottom) median colours of the image's edge strips
-    (background_resizing.py:36-57); each via the histogram-median kernel."""
+    (background_resizing.py:36-57): four strided views of the uploaded image through ONE batched launch of the
+    histogram-median kernel."""
     ctx = _native.context()
     rgba = img if img.mode == "RGBA" else img.convert("RGBA")
     dev = _upload(rgba, ctx)
     w, h = rgba.size
     strips = (dev[:, :min(strip_px, w)], dev[:, max(0, w - strip_px):],
               dev[:min(strip_px, h)], dev[max(0, h - strip_px):])
-    return tuple(median_color_device(s.contiguous(), ctx) for s in strips)
+    return tuple(median_colors_device(strips, ctx))  # four views, one launch, one wait (no .contiguous() copies)
 
 
 def _axis_variance(c1, c2) -> float:

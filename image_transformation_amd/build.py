@@ -53,6 +53,8 @@ def _stale() -> bool:
     written next to the library), not by file times: a copy of the tree need not keep them in order."""
     if not os.path.exists(LIB):
         return True
+    if not all(os.path.exists(os.path.join(CSRC, rel)) for rel in SOURCES + HEADERS):
+        return False  # a source-less (installed) tree: nothing to compare with, the library is what there is
     try:
         with open(DIGEST, "r", encoding="ascii") as f:
             return f.read().strip() != _source_digest()

@@ -154,17 +154,32 @@ def _upload(arr, ctx: _native.Context):
     return dev
 
 
-def _to_pil(canvas_dev) -> Image.Image:
-    """Device (H, W, 4) uint8 -> a PIL RGBA image over a pinned host buffer of its own (no second host
-    copy: Image.frombuffer shares the memory and marks the image read-only, so Pillow copies it by itself
-    should the caller ever modify the image in place; .save(), which is what the reference does with the
-    result (macro_placement_test.py:1513), reads it as it is).  The buffer lives as long as the image."""
+_RESULT_COPY = os.environ.get("MIC_RESULT_COPY") == "1"
+
+
+def _to_pil(canvas_dev, view: bool = False) -> Image.Image:
+    """Device (H, W, 4) uint8 -> a PIL RGBA image over a pinned host buffer of its own: the download lands in the
+    very memory the image shows (Image.frombuffer), there is no second host copy.  The image is an ordinary mutable
+    one, like the reference's result: Pillow flags frombuffer images read-only to protect a buffer it does not own,
+    but this buffer belongs to nobody else, so the flag is cleared -- px = im.load(); px[x, y] = v, paste, ImageDraw
+    all write into the image's own memory.  The page-locked block (torch's caching host allocator rounds it up to a
+    power of two) lives as long as the image; a caller that keeps many results alive can trade the copy back with
+    MIC_RESULT_COPY=1 (rows memmove'd into an ordinary Image.new, the pinned block returns to the allocator at once).
+    view=True (the package's save-only callers) keeps Pillow's read-only flag."""
     torch = _torch()
     h, w = int(canvas_dev.shape[0]), int(canvas_dev.shape[1])
     pin = _pinned(h * w * 4)
     pin.copy_(canvas_dev.reshape(-1), non_blocking=True)
     torch.cuda.current_stream(canvas_dev.device).synchronize()
-    return Image.frombuffer("RGBA", (w, h), pin.numpy(), "raw", "RGBA", 0, 1)
+    if _RESULT_COPY and not view:
+        im = Image.new("RGBA", (w, h), None)  # (colour None: Pillow leaves the pixels uninitialised)
+        if _pilmem.copy_from(im, pin.data_ptr()):
+            return im
+        return Image.frombuffer("RGBA", (w, h), pin.numpy(), "raw", "RGBA", 0, 1).copy()
+    im = Image.frombuffer("RGBA", (w, h), pin.numpy(), "raw", "RGBA", 0, 1)
+    if not view:
+        im.readonly = 0
+    return im
 
 
 class _Entry:
@@ -261,6 +276,11 @@ class Atlas(Mapping):
         torch = _torch()
         blob = torch.empty(host.numel(), dtype=torch.uint8, device=self.ctx.torch_device)
         blob.copy_(host, non_blocking=True)  # (torch's host allocator keeps `host` alive until the copy has run)
+        # the upload rides on torch's CURRENT stream; a later call may come on another one (a non-blocking side
+        # stream, a worker thread's stream): it waits for this event first (wait_ready)
+        self._ready = torch.cuda.Event()
+        self._ready.record()
+        self._ready_stream = torch.cuda.current_stream(self.ctx.torch_device).cuda_stream
         self._init_from_blob(blob, header=host.numpy()[:32 + 32 * len(objects)])
 
     def _init_from_blob(self, blob, header: Optional[np.ndarray] = None):
@@ -273,6 +293,24 @@ class Atlas(Mapping):
         _native.check(_native.lib().mic_atlas_from_device_blob(
             self.ctx.handle, _P(blob.data_ptr()), blob.numel(), _P(header.ctypes.data), ctypes.byref(h)))
         self.handle = h
+
+    _ready = None
+    _ready_stream = None
+
+    def wait_ready(self) -> None:
+        """Order torch's current stream behind the atlas upload (a no-op once the upload has completed, or when
+        the call comes on the stream that carried it)."""
+        ev = self._ready
+        if ev is None:
+            return
+        torch = _torch()
+        cur = torch.cuda.current_stream(self.ctx.torch_device)
+        if cur.cuda_stream != self._ready_stream:
+            if ev.query():
+                self._ready = None
+            else:
+                cur.wait_event(ev)
+        # same stream: in order by construction (the flag stays: a later call may come on another stream)
 
     @classmethod
     def from_blob(cls, blob, device: Optional[int] = None) -> "Atlas":
@@ -336,16 +374,40 @@ class ObjectImages(dict):
     is dropped whenever the dict is modified."""
 
     _atlas: Optional[Atlas] = None
-    _source_key = None  # set by load_object_images: identifies the files the (unmodified) dict was decoded from
+    # set by load_object_images(shared=True): identifies the files the dict's READ-ONLY views were decoded from, with
+    # the Pillow core object of every view.  Only such dicts share the process-wide device atlas of their files: a
+    # view that Pillow has copied-on-write (putalpha, paste, ImageDraw ... replace im.im and clear im.readonly) no
+    # longer shows the file's pixels and the dict then uploads an atlas of its own.  Private copies (the default
+    # load_object_images(), mutable like the reference's) always get an atlas built from the dict's own images.
+    _source_key = None
+    _cores = None
+
+    def _views_intact(self) -> bool:
+        cores = self._cores
+        if not cores or len(cores) != len(self):
+            return False
+        for k, im in self.items():
+            if not getattr(im, "readonly", 0) or getattr(im, "im", None) is not cores.get(k):
+                return False
+        return True
 
     def atlas(self, device: Optional[int] = None) -> Atlas:
+        if self._atlas is not None and self._source_key is not None and not self._views_intact():
+            self._touch()  # a view was written to since the atlas was taken from the shared cache
         if self._atlas is None or (device is not None and self._atlas.ctx.device != device):
-            if self._source_key is not None:
+            if self._source_key is not None and self._views_intact():
                 dev = _native.context(device).device
                 self._atlas = _AtlasCache.get(self._source_key, dev, lambda: Atlas(self, device))
             else:
+                self._source_key = None
                 self._atlas = Atlas(self, device)
         return self._atlas
+
+    def invalidate(self) -> None:
+        """Forget the uploaded atlas: call after editing a cutout's pixels IN PLACE (putalpha, paste, ImageDraw on an
+        image of this dict) once the dict has been used -- the dict sees its own item assignments, not writes
+        into the images it holds.  (Re-assigning the image, objects[k] = im, has the same effect.)"""
+        self._touch()
 
     _native_table = None  # (ids, widths, heights) arrays cached by flex.native_boxes
 
@@ -353,6 +415,7 @@ class ObjectImages(dict):
         self._atlas = None
         self._native_table = None
         self._source_key = None  # no longer what the files hold
+        self._cores = None
 
     def __setitem__(self, k, v):
         self._touch()
@@ -413,7 +476,11 @@ def load_object_images(results_json_path: str, shared: bool = False) -> Dict[int
         out[int(it["object_id"])] = open_rgba(path, shared)
         st = os.stat(path)
         keys.append((int(it["object_id"]), os.path.abspath(path), st.st_mtime_ns, st.st_size))
-    out._source_key = tuple(keys)  # (after the inserts above, which reset it)
+    if shared:  # (after the inserts above, which reset it)
+        out._source_key = tuple(keys)
+        out._cores = {k: getattr(im, "im", None) for k, im in out.items()}
+        if not out._views_intact():  # a Pillow without copy-on-write views: private copies, private atlas
+            out._source_key = out._cores = None
     return out
 
 
@@ -538,6 +605,8 @@ class CompositeBatch:
         self._keep: List[Any] = atlases + keep
         atl = (_P * len(atlases))(*[a.handle for a in atlases])
         h = _P()
+        for a in atlases:
+            a.wait_ready()
         with torch.cuda.device(self.ctx.torch_device):
             _native.check(_native.lib().mic_plan_create(self.ctx.handle, len(atlases), atl, self.n, jobs, filter,
                                                         ctypes.byref(h)))
@@ -564,6 +633,8 @@ class CompositeBatch:
         arr = self._outs
         if check:
             torch = _torch()
+            for a in self.atlases:
+                a.wait_ready()
             for i, out in enumerate(outs):
                 if tuple(out.shape) != self._shapes[i] or out.dtype != torch.uint8 or not out.is_contiguous() \
                         or out.device != self.ctx.torch_device:
@@ -610,6 +681,7 @@ def composite_device(atlas: Atlas, canvases: Sequence[Union[SolidCanvas, Any]],
             raise ValueError("output canvas has the wrong shape/dtype/device")
         jobs[i].out_dev = out.data_ptr()
     atl = (_P * 1)(atlas.handle)
+    atlas.wait_ready()
     with _device_guard(ctx):
         _native.check(_native.lib().mic_composite_batch(ctx.handle, 1, atl, len(sizes), jobs, filter,
                                                         _P(ctx.stream_ptr())))
@@ -676,6 +748,7 @@ def _render_native(layout_json: Any, atlas: "Atlas", canvas: Any, size: Tuple[in
             raise ValueError("canvas lives on another device than the atlas")
         bg_ptr, rgba = canvas.data_ptr(), (ctypes.c_uint8 * 4)(0, 0, 0, 0)
     out = torch.empty((H, W, 4), dtype=torch.uint8, device=ctx.torch_device)
+    atlas.wait_ready()
     with _device_guard(ctx):
         rc = _native.lib().mic_render(ctx.handle, atlas.handle, text, len(text), W, H, _P(bg_ptr) if bg_ptr else None,
                                       rgba, filter, _P(out.data_ptr()), _P(ctx.stream_ptr()), None)

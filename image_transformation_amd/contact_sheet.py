@@ -112,7 +112,7 @@ def _measure_cached(label: str, font) -> Tuple[int, int]:
 def build_labeled_contact_sheet(objects_dir: str, results_json_path: str,
                                 thumb_size: Tuple[int, int] = (256, 256), cols: int = 4,
                                 label_height: int = 72, font_size: int = 24,
-                                as_tensor: bool = False):
+                                as_tensor: bool = False, view: bool = False):
     """Drop-in for _build_labeled_contact_sheet (objects_dir is unused there too: :191).
 
     The cutouts come through load_object_images (per-process decode cache) and its resident atlas -- the same
@@ -164,12 +164,13 @@ def build_labeled_contact_sheet(objects_dir: str, results_json_path: str,
     ctx = atlas.ctx
     out = torch.empty((H.value, W.value, 4), dtype=torch.uint8, device=ctx.torch_device)
     ids_a = np.asarray(ids, np.int32)
+    atlas.wait_ready()
     with _device_guard(ctx):
         _native.check(lib.mic_contact_sheet(ctx.handle, atlas.handle, len(ids), ids_a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
                                             tw_req, th_req, cols, label_height, n_strips, ctypes.cast(strips, ctypes.c_void_p),
                                             _P(out.data_ptr()), _P(ctx.stream_ptr())))
     del keep
-    return out if as_tensor else _to_pil(out)
+    return out if as_tensor else _to_pil(out, view=view)
 
 
 # the reference's (module-private) name, for callers that import it by that name

@@ -41,8 +41,9 @@ constexpr unsigned kMaxBlocks = 512;
 // deep instead of 64.
 constexpr int kCopies = 8;
 
-// scratch layout (uint32): kGlobalCopies x { [set][channel][256], counts[2] } (set 0 = alpha > 0, set 1 =
-// alpha == 0), then the retirement ticket.  All zero between calls.  Block b flushes into copy b % 8 -- the
+// scratch layout of one image's slot (uint32): kGlobalCopies x { [set][channel][256], counts[2] } (set 0 = alpha > 0, set 1 =
+// alpha == 0), then the retirement ticket.  Zero on entry (the scratch is a double buffer: a call clears the half the
+// previous call used).  Block b flushes into copy b % 8 -- the
 // XCD it runs on, as workgroups are dealt round-robin -- so that a bin's same-address atomics (they execute
 // one after another at the memory side, ~12 ns each) are spread over eight addresses: a 4K image's 506
 // blocks put 63 adds on an address instead of 506.  The last block sums the copies.
@@ -51,7 +52,7 @@ constexpr int kCountOff = 2 * kSetWords;
 constexpr int kCopyWords = kCountOff + 16;  // counts[2] + padding to a 64-byte multiple
 constexpr int kGlobalCopies = 8;
 constexpr int kTicketOff = kGlobalCopies * kCopyWords;
-static_assert(kTicketOff < (int)kMedianScratchWords, "median scratch too small");
+static_assert(kTicketOff < (int)kMedianSlotWords, "median scratch slot too small");
 static_assert(kHistWaves == 16, "median_select maps 3 channels x 256 bins onto 1024 threads");
 
 // Small grids (a bundle background is 15 blocks) keep one copy: the contention the copies relieve is not there,
@@ -110,17 +111,36 @@ __device__ inline void hist_chunk(uint32_t p0, uint32_t p1, uint32_t p2, uint32_
     }
 }
 
-// Last block, 1024 threads: thread t carries bin (t & 255) of channel (t >> 8) (the fourth quarter
+// The kernel's work for ONE image (blockIdx.y picks it from the batch).  `stride` = pixels between rows; == w for a
+// packed image (the fast path: the image is one linear stream), anything else is a strided VIEW (fill_gradient's
+// edge strips of a resident background: 8 px wide, a whole image row apart) and takes the guarded per-pixel path.
+struct MedianImage {
+    const uint32_t *px;
+    uint32_t *hist;      // this image's scratch (kMedianSlotWords, zero on entry)
+    uint32_t *out_rgba;  // 4 bytes r, g, b, 255
+    uint64_t n_px;
+    int32_t w, stride;
+    uint32_t blocks;     // workgroups that work on this image (grid.x may be larger: other images of the batch)
+    uint32_t copies;     // global histogram copies in use (1 or kGlobalCopies)
+};
+static_assert(sizeof(MedianImage) == 48, "MedianImage layout");
+struct MedianBatch {
+    MedianImage img[kMedianMaxBatch];
+    uint32_t *zero_ptr;   // scratch the PREVIOUS call used (the other half of the double buffer): re-zeroed here, in the
+    uint32_t zero_words;  // shadow of this call's first loads, instead of at the end of that call's critical path
+    uint32_t pad;
+};
+
+// Last block of an image, 1024 threads: thread t carries bin (t & 255) of channel (t >> 8) (the fourth quarter
 // idles).  All global loads are issued up front -- they are agent-scope, a memory round trip each --
 // then one 256-bin scan per channel picks the order statistics (n-1)//2 and n//2 and thread 0 writes
 // int((lo + hi) / 2): np.median's mean of the two middle values, truncated by int().
-__device__ void median_select(const uint32_t *hist, uint32_t *out_rgba, uint32_t *wave_tot,
+__device__ void median_select(const uint32_t *hist, int copies, uint32_t *out_rgba, uint32_t *wave_tot,
                               uint32_t (*res)[2]) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int c = t >> 8, bin = t & 255;
     const bool act = c < 3;
     uint32_t n0 = 0, n1 = 0, v0 = 0, v1 = 0;
-    const int copies = median_copies(gridDim.x);
 #pragma unroll
     for (int g = 0; g < kGlobalCopies; ++g) {  // up to 32 loads issued together: one round trip
         if (g >= copies) break;
@@ -159,22 +179,28 @@ __device__ void median_select(const uint32_t *hist, uint32_t *out_rgba, uint32_t
     }
 }
 
-__global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const uint32_t *__restrict__ px, size_t n_px,
-                                                                  uint32_t *__restrict__ hist,
-                                                                  uint32_t *__restrict__ out_rgba) {
+// SELECT: true = the one-launch form (the block that retires last selects); false = the histogram half of the
+// two-launch form (median_select_kernel follows on the stream).
+template <bool SELECT>
+__global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBatch B) {
     __shared__ uint32_t lh[2 * kSetWords * kCopies];
     __shared__ uint32_t lcount[2];
     __shared__ uint32_t wave_tot[kHistWaves];
     __shared__ uint32_t res[3][2];
     __shared__ uint32_t is_last;
+    const MedianImage &I = B.img[blockIdx.y];
+    if (blockIdx.x >= I.blocks) return;  // (block-uniform; such a block takes no ticket)
+    const uint32_t *__restrict__ px = I.px;
+    const size_t n_px = I.n_px;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t n_opaque = 0, n_clear = 0;
-    const size_t stride = (size_t)gridDim.x * kHistWaves * kTripPx;
+    const size_t stride = (size_t)I.blocks * kHistWaves * kTripPx;
     size_t wbase = ((size_t)blockIdx.x * kHistWaves + wave) * kTripPx;
+    const bool packed = I.stride == I.w;  // block-uniform
     // the first trip's loads are issued before the LDS histogram is cleared: the clear (and the barrier
     // behind it) then runs in the shadow of the first memory round trip instead of in front of it
     u32x4 ld[kChunks];
-    const bool first_whole = wbase + kTripPx <= n_px;  // wave-uniform
+    const bool first_whole = packed && wbase + kTripPx <= n_px;  // wave-uniform
     if (first_whole) {
 #pragma unroll
         for (int u = 0; u < kChunks; ++u)
@@ -182,21 +208,28 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const uint32_t 
     }
     for (int i = threadIdx.x; i < 2 * kSetWords * kCopies; i += blockDim.x) lh[i] = 0;
     if (threadIdx.x < 2) lcount[threadIdx.x] = 0;
+    // the other half of the scratch double buffer: what the previous call on this context used (stream order: it has
+    // finished).  Plain stores in the shadow of the loads above; the kernel boundary publishes them to the next call.
+    if (blockIdx.y == 0 && B.zero_words) {
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < B.zero_words; i += I.blocks * blockDim.x) B.zero_ptr[i] = 0u;
+    }
     __syncthreads();
 
-    while (wbase + kTripPx <= n_px) {  // whole trips: wave-uniform, no guards
+    if (packed) {
+        while (wbase + kTripPx <= n_px) {  // whole trips: wave-uniform, no guards
 #pragma unroll
-        for (int u = 0; u < kChunks; ++u) {
-            hist_chunk<true>(ld[u][0], ld[u][1], ld[u][2], ld[u][3], true, true, true, true, lh, lane, n_opaque, n_clear);
-        }
-        wbase += stride;
-        if (wbase + kTripPx <= n_px) {
+            for (int u = 0; u < kChunks; ++u) {
+                hist_chunk<true>(ld[u][0], ld[u][1], ld[u][2], ld[u][3], true, true, true, true, lh, lane, n_opaque, n_clear);
+            }
+            wbase += stride;
+            if (wbase + kTripPx <= n_px) {
 #pragma unroll
-            for (int u = 0; u < kChunks; ++u)
-                __builtin_memcpy(&ld[u], px + wbase + (size_t)u * 256 + (size_t)lane * 4, 16);
+                for (int u = 0; u < kChunks; ++u)
+                    __builtin_memcpy(&ld[u], px + wbase + (size_t)u * 256 + (size_t)lane * 4, 16);
+            }
         }
     }
-    if (wbase < n_px) {  // the image's ragged last trip: exactly one wave of the grid gets here
+    for (; wbase < n_px; wbase += stride) {  // packed: the image's ragged last trip (one wave of the grid); a strided view: all of it
         for (int u = 0; u < kChunks; ++u) {
             const size_t cbase = wbase + (size_t)u * 256;
             if (cbase >= n_px) break;
@@ -206,10 +239,13 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const uint32_t 
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 ok[j] = i + j < n_px;
-                p[j] = ok[j] ? px[i + j] : 0u;
+                size_t at = i + j;
+                if (!packed) at = (at / (uint32_t)I.w) * (size_t)I.stride + (at % (uint32_t)I.w);
+                p[j] = ok[j] ? px[at] : 0u;
             }
             hist_chunk<false>(p[0], p[1], p[2], p[3], ok[0], ok[1], ok[2], ok[3], lh, lane, n_opaque, n_clear);
         }
+        if (packed) break;
     }
     // wave-level count reductions (shuffle), one LDS add per wave and set
     for (int off = 32; off > 0; off >>= 1) {
@@ -222,7 +258,8 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const uint32_t 
     }
     __syncthreads();
 
-    uint32_t *hist_copy = hist + (blockIdx.x & (median_copies(gridDim.x) - 1)) * kCopyWords;
+    uint32_t *hist = I.hist;
+    uint32_t *hist_copy = hist + (blockIdx.x & (I.copies - 1)) * kCopyWords;
     for (int i = threadIdx.x; i < 2 * kSetWords; i += blockDim.x) {
         uint32_t s = 0;
 #pragma unroll
@@ -230,6 +267,7 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const uint32_t 
         if (s) atomicAdd(&hist_copy[i], s);
     }
     if (threadIdx.x < 2 && lcount[threadIdx.x]) atomicAdd(&hist_copy[kCountOff + threadIdx.x], lcount[threadIdx.x]);
+    if (!SELECT) return;  // two-launch form: the kernel boundary is the hand-off
 
     // Retirement ticket, without fences.  Everything a block publishes is an agent-scope ATOMIC (performed at the
     // memory side: there are no plain stores whose dirty L2 lines a release would have to write back), and
@@ -238,36 +276,79 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const uint32_t 
     // that (1) every wave waits for its own atomics to be acknowledged (s_waitcnt vmcnt(0)) and (2) the ticket
     // add comes behind a workgroup barrier that all those waves have passed.  The release + acquire fences this
     // replaces (an L2 write-back and an L1 invalidate, ~1.7 us each) were a third of a small image's time.
+    // INVARIANT (checked by tests/test_abi.py::test_median_scratch_is_only_touched_by_atomics): between the LDS clear
+    // and this point nothing writes I.hist except atomicAdd; a plain store here would need the fences back.
+    // -DMIC_MEDIAN_FENCES restores the release/acquire pair (bisecting aid).
+#ifdef MIC_MEDIAN_FENCES
+    __atomic_thread_fence(__ATOMIC_RELEASE);  // (agent scope is the default for HIP's fences)
+#else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t ticket =
             __hip_atomic_fetch_add(hist + kTicketOff, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = ticket == gridDim.x - 1 ? 1u : 0u;
+        is_last = ticket == I.blocks - 1 ? 1u : 0u;
     }
     __syncthreads();
     if (!is_last) return;
-    median_select(hist, out_rgba, wave_tot, res);
-    __syncthreads();
-    // leave the scratch zeroed for the next call on this context (the copies this launch used, and the ticket)
-    const int used = median_copies(gridDim.x) * kCopyWords;
-    for (int i = threadIdx.x; i < used; i += blockDim.x)
-        __hip_atomic_store(hist + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x == 0) __hip_atomic_store(hist + kTicketOff, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef MIC_MEDIAN_FENCES
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+#endif
+    median_select(hist, (int)I.copies, I.out_rgba, wave_tot, res);
+    // (the scratch is NOT re-zeroed here: the next call uses the other half of the double buffer and clears this one
+    // while its own first loads are in flight)
 }
 
-// hist_dev must be zero on entry (mic_create clears it once; the kernel restores that state).
-hipError_t launch_median(const void *rgba, size_t n_px, uint32_t *hist_dev, uint32_t *out_rgba_dev,
-                         hipStream_t stream) {
-    // one trip (4 KiB) per wave before a block takes a second one: a 4K image then runs on 506 blocks (every
-    // CU, two deep) instead of 127 (half the CUs idle), a 492 x 492 bundle background on 15 instead of 4
-    const size_t per_block = kTripPx * kHistWaves;  // pixels per block per trip
-    size_t blocks = (n_px + per_block - 1) / per_block;
-    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(median_kernel, dim3((unsigned)blocks), dim3(64 * kHistWaves), 0, stream,
-                       reinterpret_cast<const uint32_t *>(rgba), n_px, hist_dev, out_rgba_dev);
-    return hipGetLastError();
+// Second launch of the two-launch form: one block per image.
+__global__ __launch_bounds__(64 * kHistWaves) void median_select_kernel(const MedianBatch B) {
+    __shared__ uint32_t wave_tot[kHistWaves];
+    __shared__ uint32_t res[3][2];
+    const MedianImage &I = B.img[blockIdx.x];
+    median_select(I.hist, (int)I.copies, I.out_rgba, wave_tot, res);
+}
+
+// scratch_dev: 2 * kMedianMaxBatch slots of kMedianSlotWords (a double buffer), zero on entry of the first call; the
+// launcher alternates halves with *phase and hands the half used by the previous call to this one for clearing.
+hipError_t launch_median_batch(int k, const MedianView *views, uint32_t *const *out_rgba_dev, uint32_t *scratch_dev,
+                               MedianState *state, bool two_launches, hipStream_t stream) {
+    if (k <= 0 || k > kMedianMaxBatch) return hipErrorInvalidValue;
+    MedianBatch B{};
+    const uint32_t half = (uint32_t)kMedianMaxBatch * (uint32_t)kMedianSlotWords;
+    uint32_t *mine = scratch_dev + (size_t)(state->phase & 1) * half;
+    unsigned grid_x = 1;
+    for (int i = 0; i < k; ++i) {
+        const MedianView &v = views[i];
+        MedianImage &I = B.img[i];
+        I.px = static_cast<const uint32_t *>(v.px);
+        I.hist = mine + (size_t)i * kMedianSlotWords;
+        I.out_rgba = out_rgba_dev[i];
+        I.n_px = (uint64_t)v.w * v.h;
+        I.w = v.w;
+        I.stride = v.stride_px;
+        // one trip (4 KiB) per wave before a block takes a second one: a 4K image then runs on 506 blocks (every
+        // CU, two deep) instead of 127 (half the CUs idle), a 492 x 492 bundle background on 15 instead of 4
+        const size_t per_block = kTripPx * kHistWaves;  // pixels per block per trip
+        size_t blocks = (I.n_px + per_block - 1) / per_block;
+        blocks = std::min<size_t>(std::max<size_t>(blocks, 1), kMaxBlocks);
+        I.blocks = (uint32_t)blocks;
+        I.copies = (uint32_t)median_copies((unsigned)blocks);
+        grid_x = std::max(grid_x, (unsigned)blocks);
+    }
+    B.zero_ptr = scratch_dev + (size_t)((state->phase + 1) & 1) * half;
+    B.zero_words = state->prev_words;
+    if (two_launches) {
+        hipLaunchKernelGGL(median_kernel<false>, dim3(grid_x, (unsigned)k), dim3(64 * kHistWaves), 0, stream, B);
+        hipLaunchKernelGGL(median_select_kernel, dim3((unsigned)k), dim3(64 * kHistWaves), 0, stream, B);
+    } else {
+        hipLaunchKernelGGL(median_kernel<true>, dim3(grid_x, (unsigned)k), dim3(64 * kHistWaves), 0, stream, B);
+    }
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) {
+        state->phase ^= 1u;
+        state->prev_words = (uint32_t)k * (uint32_t)kMedianSlotWords;  // slots 0..k-1 of the half just used
+    }
+    return e;
 }
 
 }  // namespace mic

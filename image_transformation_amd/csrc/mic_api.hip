@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <climits>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -51,7 +52,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *mic_last_error(void) { return g_err; }
-extern "C" int mic_version(void) { return (1 << 16) | 6; }  // 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
+extern "C" int mic_version(void) { return (1 << 16) | 7; }  // 1.7: + mic_median_rgb_batch, 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
 
 // ------------------------------------------------------------------------------------ blob layout
 namespace {
@@ -171,7 +172,9 @@ struct mic_ctx {
     // Work units a call's resampled layers must add up to before they take the marching kernel (two workgroups
     // per CU); MIC_RS_MARCH_MIN_UNITS at mic_create (tests set 0 to run every qualifying layer through it).
     int64_t march_min_units = 512;
-    uint32_t *median_scratch = nullptr;  // device: histogram words + 1 result word
+    uint32_t *median_scratch = nullptr;  // device: two sets of histogram slots (a double buffer) + kMedianMaxBatch result words
+    MedianState median_state;            // which half the next call works in, what the previous one left to clear
+    bool median_two_launches = false;    // MIC_MEDIAN_TWO_LAUNCHES=1: histogram kernel + select kernel (measurement aid)
     uint32_t *gradient_table = nullptr;  // device: fill_gradient's per-position colours (allocated on first use)
     uint32_t *median_host = nullptr;     // pinned
     hipStream_t last_stream = nullptr;
@@ -238,9 +241,10 @@ extern "C" int mic_create(int device, mic_ctx **out) {
             return fail(MIC_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
         }
     }
-    e = hipMalloc(&ctx->median_scratch, (kMedianScratchWords + 8) * sizeof(uint32_t));
-    // zeroed once: the median kernel's last block leaves it zeroed again after every call
-    if (e == hipSuccess) e = hipMemset(ctx->median_scratch, 0, (kMedianScratchWords + 8) * sizeof(uint32_t));
+    if (const char *tl = getenv("MIC_MEDIAN_TWO_LAUNCHES")) ctx->median_two_launches = atoi(tl) != 0;
+    e = hipMalloc(&ctx->median_scratch, (kMedianScratchWords + 64) * sizeof(uint32_t));
+    // zeroed once: every median call clears the half of the double buffer the call before it used
+    if (e == hipSuccess) e = hipMemset(ctx->median_scratch, 0, (kMedianScratchWords + 64) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->median_host), 64, 0);
     if (e != hipSuccess) {
         mic_destroy(ctx);
@@ -535,7 +539,10 @@ extern "C" int mic_atlas_destroy(mic_atlas *atlas) {
 // atlas the first time).  Runs on the stream of the calling entry point (job table through the staging
 // ring): the context is driven from one stream at a time and adopt_stream() orders a later stream behind
 // this one, so every later launch sees the copies without a device-wide synchronisation here.
-static int atlas_ensure_planar(const mic_atlas *A, const std::vector<int> &need, hipStream_t stream) {
+// Split in two: the buffer is allocated (and every cutout's address in it fixed) when a plan is BUILT, the conversion
+// kernels are enqueued when a plan is first RUN, on that run's stream -- mic_plan_create has no stream of its own, and
+// the stream the caller uploaded the blob on is the one it will run on (or has ordered before it).
+static int atlas_planar_alloc(const mic_atlas *A) {
     mic_ctx *ctx = A->ctx;
     const size_t n = A->entries.size();
     if (!A->planar) {
@@ -558,6 +565,12 @@ static int atlas_ensure_planar(const mic_atlas *A, const std::vector<int> &need,
         A->planar_built.assign(n, 0);
         A->planar = std::move(buf);
     }
+    return MIC_OK;
+}
+
+static int atlas_planar_build(const mic_atlas *A, const std::vector<int> &need, hipStream_t stream) {
+    mic_ctx *ctx = A->ctx;
+    if (int rc = atlas_planar_alloc(A)) return rc;
     std::vector<PlanarJob> jobs;
     std::vector<int> building;  // marked built only once their kernel has been enqueued
     int64_t max_items = 0;
@@ -841,6 +854,9 @@ struct mic_plan {
     std::vector<Job> ordered;  // hot jobs first, rebuilt per run
     std::vector<Layer> layers;
     PassTables pt;
+    // cutouts whose planar premultiplied copy the marching kernel reads: converted by the first run that finds them
+    // unconverted, on that run's stream (the atlases outlive the runs, mic.h)
+    std::vector<std::pair<const mic_atlas *, std::vector<int>>> planar_todo;
     void *scratch = nullptr;   // resampled layers (persistent plans own it; transient ones borrow ctx->arena)
     size_t scratch_bytes = 0;
     void *tables_dev = nullptr;  // persistent plans: jobs | layers | h passes | v passes
@@ -1013,12 +1029,14 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
         if (!planar_need[(size_t)a].empty()) {
             std::vector<int> entries;
             for (const auto &ne : planar_need[(size_t)a]) entries.push_back(ne.first);
-            if (int rc = atlas_ensure_planar(A, entries, stream)) return rc;
+            if (int rc = atlas_planar_alloc(A)) return rc;
+            P->planar_todo.push_back({A, std::move(entries)});
         }
         if (!A->planar) continue;
         bool used = false;
-        for (ResizePlan &rp : plans) {  // marching layers need the copy; tile-kernel layers take it where it exists
-            if (rp.atlas != a || !(rp.march || rp.tx16 > 0) || !A->planar_built[(size_t)rp.entry]) continue;
+        for (ResizePlan &rp : plans) {  // marching layers need the copy (converted by the first run, plan_submit);
+            // tile-kernel layers take it where an earlier call has already converted it
+            if (rp.atlas != a || !(rp.march || (rp.tx16 > 0 && A->planar_built[(size_t)rp.entry]))) continue;
             rp.planar_src = reinterpret_cast<uint64_t>(A->planar->dev) + A->planar_off[(size_t)rp.entry];
             rp.planar_pitch = A->planar_pitch[(size_t)rp.entry];
             used = true;
@@ -1176,6 +1194,12 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     }
     const Job *jobs_dev = one ? nullptr : (P->persistent ? slot_tab->dev : reinterpret_cast<const Job *>(dp));
 
+    for (const auto &todo : P->planar_todo) {
+        bool missing = false;
+        for (int e : todo.second) missing |= !todo.first->planar_built[(size_t)e];
+        if (missing)
+            if (int rc = atlas_planar_build(todo.first, todo.second, stream)) return rc;
+    }
     const bool prof = ctx->profiling && ctx->prof_calls < ctx->prof_max && (ctx->prof_seen++ % ctx->prof_every) == 0;
     hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], stream));
@@ -1463,6 +1487,30 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
 }
 
 // ------------------------------------------------------------------------------------ background
+static int median_view(const mic_image_view &v, int i, MedianView *out) {
+    if (!v.rgba_dev || v.width <= 0 || v.height <= 0 || v.width > kMaxDim || v.height > kMaxDim)
+        return fail(MIC_ERR_INVALID, "mic_median_rgb: image %d: bad pointer or size", i);
+    const int64_t stride = v.stride_bytes == 0 ? (int64_t)v.width * 4 : v.stride_bytes;
+    if (stride % 4 != 0 || stride < (int64_t)v.width * 4 || stride / 4 > INT32_MAX ||
+        reinterpret_cast<uintptr_t>(v.rgba_dev) % 4 != 0)
+        return fail(MIC_ERR_INVALID, "mic_median_rgb: image %d: stride must be a multiple of 4 and >= width * 4, pixels 4-byte aligned", i);
+    out->px = v.rgba_dev;
+    out->w = v.width;
+    out->h = v.height;
+    // a one-row view, or rows that follow each other without a gap, is a packed image whatever its stride says
+    out->stride_px = (v.height == 1 || stride == (int64_t)v.width * 4) ? v.width : (int32_t)(stride / 4);
+    return MIC_OK;
+}
+
+// results of call chunk: device words res_dev[0..k)
+static int median_launch(mic_ctx *ctx, int k, const mic_image_view *views, uint32_t *const *outs, hipStream_t stream) {
+    MedianView mv[kMedianMaxBatch];
+    for (int i = 0; i < k; ++i)
+        if (int rc = median_view(views[i], i, &mv[i])) return rc;
+    HIP_TRY(launch_median_batch(k, mv, outs, ctx->median_scratch, &ctx->median_state, ctx->median_two_launches, stream));
+    return MIC_OK;
+}
+
 extern "C" int mic_median_rgb_dev(mic_ctx *ctx, const void *rgba_dev, int32_t width, int32_t height,
                                   void *rgba_out_dev, void *stream_v) {
     CTX_ENTER(ctx);
@@ -1470,24 +1518,38 @@ extern "C" int mic_median_rgb_dev(mic_ctx *ctx, const void *rgba_dev, int32_t wi
     if (!rgba_dev || !rgba_out_dev || width <= 0 || height <= 0)
         return fail(MIC_ERR_INVALID, "mic_median_rgb: bad arguments");
     if (int rc = adopt_stream(ctx, stream)) return rc;
-    HIP_TRY(launch_median(rgba_dev, (size_t)width * height, ctx->median_scratch,
-                          static_cast<uint32_t *>(rgba_out_dev), stream));
-    return MIC_OK;
+    const mic_image_view v{rgba_dev, width, height, 0};
+    uint32_t *out = static_cast<uint32_t *>(rgba_out_dev);
+    return median_launch(ctx, 1, &v, &out, stream);
 }
 
 extern "C" int mic_median_rgb(mic_ctx *ctx, const void *rgba_dev, int32_t width, int32_t height,
                               uint8_t out_rgb[3], void *stream_v) {
-    if (!out_rgb) return fail(MIC_ERR_INVALID, "mic_median_rgb: null result");
+    const mic_image_view v{rgba_dev, width, height, 0};
+    return mic_median_rgb_batch(ctx, 1, &v, out_rgb, stream_v);
+}
+
+extern "C" int mic_median_rgb_batch(mic_ctx *ctx, int32_t n, const mic_image_view *views, uint8_t *out_rgb,
+                                    void *stream_v) {
+    if (n < 0 || (n > 0 && (!views || !out_rgb))) return fail(MIC_ERR_INVALID, "mic_median_rgb_batch: bad arguments");
     CTX_ENTER(ctx);  // held across the copy-back: median_host is context state
-    uint32_t *res_dev = ctx->median_scratch + kMedianScratchWords;
-    if (int rc = mic_median_rgb_dev(ctx, rgba_dev, width, height, res_dev, stream_v)) return rc;
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    HIP_TRY(hipMemcpyAsync(ctx->median_host, res_dev, 4, hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    const uint32_t v = ctx->median_host[0];
-    out_rgb[0] = (uint8_t)(v & 255u);
-    out_rgb[1] = (uint8_t)((v >> 8) & 255u);
-    out_rgb[2] = (uint8_t)((v >> 16) & 255u);
+    if (int rc = adopt_stream(ctx, stream)) return rc;
+    uint32_t *res_dev = ctx->median_scratch + kMedianScratchWords;
+    for (int32_t at = 0; at < n; at += kMedianMaxBatch) {  // one launch, one copy-back, one wait per 16 images
+        const int k = std::min<int32_t>(kMedianMaxBatch, n - at);
+        uint32_t *outs[kMedianMaxBatch];
+        for (int i = 0; i < k; ++i) outs[i] = res_dev + i;
+        if (int rc = median_launch(ctx, k, views + at, outs, stream)) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->median_host, res_dev, 4 * (size_t)k, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (int i = 0; i < k; ++i) {
+            const uint32_t v = ctx->median_host[i];
+            out_rgb[3 * (size_t)(at + i) + 0] = (uint8_t)(v & 255u);
+            out_rgb[3 * (size_t)(at + i) + 1] = (uint8_t)((v >> 8) & 255u);
+            out_rgb[3 * (size_t)(at + i) + 2] = (uint8_t)((v >> 16) & 255u);
+        }
+    }
     return MIC_OK;
 }
 

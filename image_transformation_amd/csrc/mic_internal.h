@@ -173,10 +173,23 @@ struct alignas(16) OutlineRect {
 static_assert(sizeof(OutlineRect) == 48, "OutlineRect layout");
 hipError_t launch_rect_outlines(void *out, int W, int H, const OutlineRect *rects_dev, int n, int width,
                                 hipStream_t stream);
-// hist: 8 copies of { uint32 [2][3][256] + counts[2] (+ padding) } + ticket; must be zero on entry, the kernel
-// leaves it zeroed.
-hipError_t launch_median(const void *rgba, size_t n_px, uint32_t *hist_dev, uint32_t *out_rgba_dev,
-                         hipStream_t stream);
-constexpr size_t kMedianScratchWords = 8 * (2 * 3 * 256 + 16) + 8;
+// Median colour of up to kMedianMaxBatch images in one launch (kernels_median.hip).  Per image a scratch slot of
+// 8 copies of { uint32 [2][3][256] + counts[2] (+ padding) } + ticket; the context holds TWO sets of slots (a double
+// buffer, kMedianScratchWords in all, zeroed once by mic_create): a call works in one half and clears, in the shadow
+// of its first loads, what the previous call left in the other.
+constexpr int kMedianMaxBatch = 16;
+constexpr size_t kMedianSlotWords = 8 * (2 * 3 * 256 + 16) + 8;
+constexpr size_t kMedianScratchWords = 2 * kMedianMaxBatch * kMedianSlotWords;
+struct MedianView {
+    const void *px;     // device RGBA
+    int32_t w, h;
+    int32_t stride_px;  // pixels between rows (== w: a packed image)
+};
+struct MedianState {
+    uint32_t phase = 0;       // half of the double buffer the next call works in
+    uint32_t prev_words = 0;  // words of the other half the previous call used
+};
+hipError_t launch_median_batch(int k, const MedianView *views, uint32_t *const *out_rgba_dev, uint32_t *scratch_dev,
+                               MedianState *state, bool two_launches, hipStream_t stream);
 
 }  // namespace mic

@@ -103,7 +103,7 @@ def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, ori
     results_json = bundle / "results.json"
     bg_path = bundle / "background.png"
     ow, oh = original_size
-    sheet = build_labeled_contact_sheet(str(bundle / "objects"), str(results_json))
+    sheet = build_labeled_contact_sheet(str(bundle / "objects"), str(results_json), view=True)
     canvas: SolidCanvas = solid_canvas(str(bg_path), canvas_size)
     objects = load_object_images(str(results_json), shared=True)  # resident atlas on first use
     atlas = objects.atlas()
@@ -130,7 +130,7 @@ def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, ori
                            for p in placements],
         }
         out_dev = composite_device(atlas, [canvas], [coerce_placements(atlas, final_json["placements"])])[0]
-        draft = _to_pil(out_dev)
+        draft = _to_pil(out_dev, view=True)  # save-only here: a read-only view of the download buffer
         drafts.append(draft)
         all_placements.append(final_json["placements"])
         if save:

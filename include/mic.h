@@ -153,6 +153,16 @@ int mic_median_rgb(mic_ctx *ctx, const void *rgba_dev, int32_t width, int32_t he
 /* Same, result left on the device as 4 bytes r,g,b,255 at rgba_out_dev (no host sync).      */
 int mic_median_rgb_dev(mic_ctx *ctx, const void *rgba_dev, int32_t width, int32_t height,
                        void *rgba_out_dev, void *stream);
+/* The same for n images in ONE launch, one copy-back and one stream wait per 16 images: fill_gradient's four
+ * 8-pixel edge strips (background_resizing.py:36-57) are four VIEWS of the resident background -- the strided form
+ * (stride_bytes = the parent image's row pitch; 0 = packed, width * 4) needs no .contiguous() copy.  out_rgb: n x 3
+ * bytes.  Pixels 4-byte aligned, stride a multiple of 4 and >= width * 4.                                     */
+typedef struct mic_image_view {
+    const void *rgba_dev;
+    int32_t width, height;
+    int64_t stride_bytes;
+} mic_image_view;
+int mic_median_rgb_batch(mic_ctx *ctx, int32_t n, const mic_image_view *views, uint8_t *out_rgb, void *stream);
 /* Image.new("RGBA", (w,h), colour) on the device (background_resizing.py:32).               */
 int mic_fill_solid(mic_ctx *ctx, void *out_dev, int32_t width, int32_t height,
                    const uint8_t rgba[4], void *stream);

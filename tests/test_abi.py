@@ -43,18 +43,42 @@ def test_struct_layouts_match_header(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mic.h"\n'
-                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mic_placement), offsetof(mic_placement, box), '
+                   'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mic_placement), offsetof(mic_placement, box), '
                    'sizeof(mic_job), offsetof(mic_job, out_dev), sizeof(mic_stats), offsetof(mic_stats, marched_layers), '
-                   'sizeof(mic_label_strip), offsetof(mic_label_strip, coverage_host)); return 0; }\n')
+                   'sizeof(mic_label_strip), offsetof(mic_label_strip, coverage_host), '
+                   'sizeof(mic_image_view), offsetof(mic_image_view, stride_bytes)); return 0; }\n')
     exe = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     mine = [ctypes.sizeof(_native.Placement), _native.Placement.box.offset,
             ctypes.sizeof(_native.Job), _native.Job.out_dev.offset,
             ctypes.sizeof(_native.Stats), _native.Stats.marched_layers.offset,
-            ctypes.sizeof(_native.LabelStrip), _native.LabelStrip.coverage_host.offset]
+            ctypes.sizeof(_native.LabelStrip), _native.LabelStrip.coverage_host.offset,
+            ctypes.sizeof(_native.ImageView), _native.ImageView.stride_bytes.offset]
     assert got == mine, (got, mine)
     assert got[0] == 24 and got[2] == 40 and got[4] == 64
+
+
+def test_binding_refuses_another_abi_version(built_lib, monkeypatch):
+    """An alternative build (MIC_LIB) of another ABI minor would fill other struct layouts: refused at load time."""
+    from image_transformation_amd import _native
+    monkeypatch.setattr(_native, "ABI_VERSION", (1, 99))
+    with pytest.raises(RuntimeError, match="reports ABI"):
+        _native.load_library(built_lib)
+
+
+def test_median_scratch_is_only_touched_by_atomics():
+    """kernels_median.hip hands its histogram to the last block WITHOUT release/acquire fences; that is only valid
+    while every write to the scratch between the LDS clear and the ticket is an agent-scope atomic.
+    Static check of the source: inside median_kernel no plain store goes through hist / hist_copy / I.hist."""
+    with open(os.path.join(ROOT, "image_transformation_amd", "csrc", "kernels_median.hip"), encoding="utf-8") as f:
+        src = f.read()
+    body = src[src.index("void median_kernel(const MedianBatch B)"):src.index("// Second launch of the two-launch form")]
+    body = re.sub(r"//[^\n]*", "", body)
+    for m in re.finditer(r"\b(hist|hist_copy)\s*(\[[^\]]*\])?\s*(\[[^\]]*\])?\s*([-+|&^]?=)(?!=)", body):
+        line = body[body.rfind("\n", 0, m.start()) + 1:body.find("\n", m.end())]
+        assert re.search(r"uint32_t \*hist(_copy)? =", line), f"plain store to the median scratch: {line.strip()}"
+    assert "atomicAdd(&hist_copy[" in body and "MIC_MEDIAN_FENCES" in body
 
 
 def test_host_only_entry_points(built_lib):
@@ -186,3 +210,52 @@ def test_shared_views_of_the_decode_cache_are_copy_on_write(tmp_path):
     assert b.getpixel((3, 3)) == (9, 9, 9, 9) and c.getpixel((0, 0)) == (0, 0, 0, 255)
     assert open_rgba(p).getpixel((0, 0)) == (10, 20, 30, 40)            # the plain call: a private copy, as before
     assert open_rgba(p, shared=True).getpixel((3, 3)) == (10, 20, 30, 40)
+
+
+def test_atlas_cache_is_only_for_intact_shared_views(tmp_path, monkeypatch):
+    """the process-wide device atlas of a bundle's FILES may only serve dicts whose images still
+    show the files' pixels.  Private copies (the default load) never use it; shared read-only views do until Pillow
+    copies one on write (im.im replaced, readonly cleared).  Atlas construction is stubbed: no GPU here."""
+    import json
+    from PIL import Image
+    from image_transformation_amd import compositor
+
+    for i in range(2):
+        Image.new("RGBA", (6 + i, 5), (10 * i, 20, 30, 255)).save(tmp_path / f"o{i}.png")
+    rj = tmp_path / "results.json"
+    rj.write_text(json.dumps([{"object_id": i + 1, "filename": f"o{i}.png"} for i in range(2)]))
+
+    built = []
+
+    class FakeCtx:
+        device = 0
+
+    class FakeAtlas:
+        def __init__(self, objects, device=None):
+            self.ctx = FakeCtx()
+            self.pixels = {k: v.tobytes() for k, v in objects.items()}
+            built.append(self)
+
+    monkeypatch.setattr(compositor, "Atlas", FakeAtlas)
+    monkeypatch.setattr(compositor._native, "context", lambda device=None: FakeCtx())
+    compositor._AtlasCache._items.clear()
+
+    private = compositor.load_object_images(str(rj))
+    assert private._source_key is None
+    private[1].putalpha(7)                                  # in-place edit BEFORE first use
+    a = private.atlas()
+    assert a.pixels[1] == private[1].tobytes() and private[1].getpixel((0, 0))[3] == 7
+    assert not compositor._AtlasCache._items                # private copies never touch the shared cache
+
+    s1 = compositor.load_object_images(str(rj), shared=True)
+    s2 = compositor.load_object_images(str(rj), shared=True)
+    assert s1._source_key is not None and s1.atlas() is s2.atlas() and len(built) == 2
+    s2[2].putalpha(9)                                       # Pillow copies the view before it writes
+    assert s2[2].readonly == 0
+    a2 = s2.atlas()
+    assert a2 is not s1.atlas() and a2.pixels[2] == s2[2].tobytes() and s2._source_key is None
+    assert s1.atlas() is built[1]                           # the untouched dict still shares the files' atlas
+    s3 = compositor.load_object_images(str(rj), shared=True)
+    assert s3.atlas() is built[1]
+    s3.invalidate()
+    assert s3.atlas() is not built[1]

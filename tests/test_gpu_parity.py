@@ -546,3 +546,134 @@ def test_plan_job_table_cache(gpu):
         for t in sets[k]:
             t.zero_()
             used.discard(k)
+
+
+# ------------------------------------------------------------------------------------------ round 3
+def test_median_batch_strided_views_and_long_batches(gpu):
+    """mic_median_rgb_batch: several images -- packed, strided views (fill_gradient's edge strips), one-row and
+    one-column views, all-transparent, > 16 images (two launches) -- each equal to the oracle on the same pixels; the
+    scratch double buffer survives alternating batch sizes."""
+    import torch
+    from image_transformation_amd.background_resizing import median_color_device, median_colors_device
+    rng = np.random.default_rng(31)
+    base = rng.integers(0, 256, (250, 970, 4), dtype=np.uint8)
+    base[:, :, 3] = np.where(rng.random((250, 970)) < 0.3, 0, base[:, :, 3])
+    dev = torch.from_numpy(base).to(gpu.torch_device)
+    views = [dev[:, :8], dev[:, -8:], dev[:8], dev[-8:], dev, dev[3:4], dev[:, 5:6], dev[10:200:1, 100:900]]
+    want = [oracle.median_rgb(np.ascontiguousarray(v.cpu().numpy())) for v in views]
+    for _ in range(3):
+        assert median_colors_device(views) == want
+        assert median_color_device(dev) == want[4]
+    clear = torch.zeros((40, 50, 4), dtype=torch.uint8, device=gpu.torch_device)
+    clear[:, :, :3] = torch.randint(0, 256, (40, 50, 3), dtype=torch.uint8, device=gpu.torch_device)
+    big = torch.randint(0, 256, (1100, 1900, 4), dtype=torch.uint8, device=gpu.torch_device)  # > 32 blocks: 8 copies
+    many = [clear, big, big[:, 7:1500], big[500:]] + [dev[k:k + 9 + k, k:k + 31] for k in range(0, 34, 2)]
+    assert len(many) == 21
+    got = median_colors_device(many)
+    for v, g in zip(many, got):
+        assert g == oracle.median_rgb(np.ascontiguousarray(v.cpu().numpy()))
+    assert median_colors_device([]) == []
+    with pytest.raises(ValueError):
+        median_colors_device([dev[:, ::2]])  # pixels not adjacent
+
+
+def test_median_two_launch_form_agrees(gpu):
+    """The two-launch form of the median (histogram kernel + select kernel, MIC_MEDIAN_TWO_LAUNCHES=1 at mic_create;
+    kept as the measured alternative to the one-launch ticket) gives the same colours."""
+    import ctypes
+    import torch
+    from image_transformation_amd import _native
+    lib = _native.lib()
+    os.environ["MIC_MEDIAN_TWO_LAUNCHES"] = "1"
+    try:
+        h = ctypes.c_void_p()
+        _native.check(lib.mic_create(gpu.device, ctypes.byref(h)))
+    finally:
+        del os.environ["MIC_MEDIAN_TWO_LAUNCHES"]
+    try:
+        rng = np.random.default_rng(32)
+        for shape in ((492, 492), (2160, 3840), (1, 1), (37, 1001)):
+            a = rng.integers(0, 256, shape + (4,), dtype=np.uint8)
+            d = torch.from_numpy(a).to(gpu.torch_device)
+            out = (ctypes.c_uint8 * 3)()
+            for _ in range(2):
+                _native.check(lib.mic_median_rgb(h, ctypes.c_void_p(d.data_ptr()), shape[1], shape[0], out,
+                                                 ctypes.c_void_p(gpu.stream_ptr())))
+                assert tuple(out) == oracle.median_rgb(a), shape
+    finally:
+        lib.mic_destroy(h)
+
+
+def test_atlas_and_plan_built_on_a_side_stream(gpu):
+    """an Atlas uploaded and a CompositeBatch created inside `with torch.cuda.stream(s)` (a
+    non-blocking side stream), LANCZOS layers included (the marching kernel's planar copies are converted by the first
+    RUN, on the run's stream) -- then run on that stream and again on the default stream."""
+    import torch
+    from image_transformation_amd import _native
+    from image_transformation_amd.compositor import Atlas, CompositeBatch, SolidCanvas, coerce_placements
+    syn = cases.synthetic
+    lib = _native.lib()
+    size, objs, pl = syn.placements_workload(1920, 1080, 24, 77, "soft")
+    want = oracle.composite(_solid(*size), objs, pl)
+    # a context that routes every qualifying layer through the marching kernel (planar copies needed)
+    os.environ["MIC_RS_MARCH_MIN_UNITS"] = "0"
+    try:
+        import ctypes
+        h = ctypes.c_void_p()
+        _native.check(lib.mic_create(gpu.device, ctypes.byref(h)))
+    finally:
+        del os.environ["MIC_RS_MARCH_MIN_UNITS"]
+    lib.mic_destroy(h)  # (only to prove creation works with the knob; the package context below uses its default)
+    s = torch.cuda.Stream(device=gpu.torch_device)
+    with torch.cuda.stream(s):
+        filler = torch.empty(256 << 20, dtype=torch.uint8, device=gpu.torch_device)
+        filler.fill_(1)  # keeps the side stream busy while the upload and the plan are enqueued behind it
+        atlas = Atlas(objs)
+        plan = CompositeBatch(atlas, [SolidCanvas(size, syn.SOLID_BG)], [coerce_placements(atlas, pl)])
+        out_side = plan.run()[0]
+    out_default = plan.run()[0]  # torch's default stream: must wait for the upload on `s`
+    torch.cuda.synchronize()
+    assert np.array_equal(out_default.cpu().numpy(), want)
+    assert np.array_equal(out_side.cpu().numpy(), want)
+    assert plan.stats()["resampled_layers"] > 0
+
+
+def test_results_are_ordinary_mutable_images(gpu):
+    """The PIL image composite() returns behaves like the reference's: writable through load(), paste, ImageDraw; and
+    edits never leak into a later result."""
+    from PIL import ImageDraw
+    from image_transformation_amd.compositor import composite
+    rng = np.random.default_rng(8)
+    bg = _img(rng.integers(0, 256, (60, 80, 4), dtype=np.uint8))
+    objs = {1: _img(rng.integers(0, 256, (20, 30, 4), dtype=np.uint8))}
+    pl = [{"object_id": 1, "box": [5, 6, 35, 26]}]
+    want = oracle.composite(np.array(bg), {1: np.array(objs[1])}, pl)
+    out = composite(bg, objs, pl)
+    assert np.array_equal(np.array(out), want)
+    px = out.load()
+    px[0, 0] = (1, 2, 3, 4)
+    ImageDraw.Draw(out).rectangle([10, 10, 20, 20], fill=(9, 9, 9, 9))
+    out.paste((7, 7, 7, 7), (0, 30, 5, 35))
+    assert out.getpixel((0, 0)) == (1, 2, 3, 4) and out.getpixel((15, 15)) == (9, 9, 9, 9) and out.getpixel((2, 32)) == (7, 7, 7, 7)
+    again = composite(bg, objs, pl)
+    assert np.array_equal(np.array(again), want)
+
+
+def test_in_place_edit_of_a_loaded_cutout_is_seen(gpu, tmp_path):
+    """load_object_images() -> putalpha in place -> composite: the edited pixels are composited
+    (the shared atlas of the bundle's files must not be used), also when an earlier load of the same files has
+    already put that atlas into the cache (the contact sheet does)."""
+    from image_transformation_amd.compositor import composite, load_object_images
+    from image_transformation_amd.contact_sheet import build_labeled_contact_sheet
+    base = os.path.join(cases.BUNDLE_DIR, "squarespace")
+    rj = os.path.join(base, "results.json")
+    build_labeled_contact_sheet(os.path.join(base, "objects"), rj)  # fills the cache with the files' atlas
+    objs = load_object_images(rj)
+    objs[2].putalpha(90)
+    bg = _img(_solid(492, 492))
+    pl = [{"object_id": 2, "box": [10, 20, 10 + objs[2].size[0], 20 + objs[2].size[1]]}, {"object_id": 1, "box": [0, 0, 300, 90]}]
+    want = oracle.composite(np.array(bg), {k: np.array(v) for k, v in objs.items()}, pl)
+    assert np.array_equal(np.array(composite(bg, objs, pl)), want)
+    shared = load_object_images(rj, shared=True)
+    shared[2].putalpha(90)  # copy-on-write view: detected, private atlas
+    assert np.array_equal(np.array(composite(bg, shared, pl)), want)

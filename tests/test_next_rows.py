@@ -180,7 +180,14 @@ def test_run_layouts_harness_matches_reference_goldens(golden_dir, tmp_path):
     from PIL import Image
     saved = np.array(Image.open(os.path.join(out, "iteration_00", "final_product", "draft_macro_iter_00.png")).convert("RGBA"))
     assert np.array_equal(saved, arrays["squarespace_1x1"])
-    assert os.path.exists(os.path.join(out, "iteration_00", "vlm_input_image", "contact_sheet.png"))
+    # every PNG artifact is written by libmic's own encoder (png.py): re-opened with Pillow, pixels identical
+    for i in range(3):
+        again = np.array(Image.open(os.path.join(out, f"iteration_{i:02d}", "final_product", f"draft_macro_iter_{i:02d}.png")))
+        assert again.shape == (492, 492, 4) and np.array_equal(again, np.array(res["drafts"][i])), i
+    sheet_png = Image.open(os.path.join(out, "iteration_00", "vlm_input_image", "contact_sheet.png"))
+    assert sheet_png.mode == "RGBA" and np.array_equal(np.array(sheet_png), np.array(res["contact_sheet"]))
+    with open(os.path.join(out, "iteration_00", "final_product", "draft_macro_iter_00.png"), "rb") as f:
+        assert f.read(8) == b"\x89PNG\r\n\x1a\n"
     canvas_png = np.array(Image.open(os.path.join(out, "iteration_00", "vlm_input_image", "canvas.png")).convert("RGBA"))
     assert canvas_png.shape == (492, 492, 4) and (canvas_png == np.array([220, 238, 245, 255], np.uint8)).all()
     for i in range(3):  # overlay_debug_iter_XX.png (macro_placement_test.py:1514, :1700) == the oracle's drawing
