@@ -851,7 +851,8 @@ def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_
         canvas=list(wide[0][0]),
         **batch_leg(ctx, c4atlas, [SolidCanvas(s, synthetic.SOLID_BG) for s, _ in wide],
                     [coerce_placements(c4atlas, flex.layout_to_placements(l, c4atlas, s)) for s, l in wide]))
-    mixed = variants[:B]  # ratios cycle 9:16, 1:1, 16:9, 21:9: four of each class
+    mixed = variants  # BASELINE configs[3]'s whole batch (what `--workload c4` / `c4_strong` time by the wall clock at
+    # N = 1): ratios cycle 9:16, 1:1, 16:9, 21:9, sixteen canvases of each class in one launch
     result["mixed_c4_batch"] = dict(
         canvases=sorted({tuple(s) for s, _ in mixed}),
         **batch_leg(ctx, c4atlas, [SolidCanvas(s, synthetic.SOLID_BG) for s, _ in mixed],

@@ -181,7 +181,9 @@ __device__ void median_select(const uint32_t *hist, int copies, uint32_t *out_rg
 
 // SELECT: true = the one-launch form (the block that retires last selects); false = the histogram half of the
 // two-launch form (median_select_kernel follows on the stream).
-template <bool SELECT>
+// STRIDED: some image of the batch is a strided view (the instantiation for packed images carries none of the
+// per-pixel index arithmetic).
+template <bool SELECT, bool STRIDED>
 __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBatch B) {
     __shared__ uint32_t lh[2 * kSetWords * kCopies];
     __shared__ uint32_t lcount[2];
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBat
     uint32_t n_opaque = 0, n_clear = 0;
     const size_t stride = (size_t)I.blocks * kHistWaves * kTripPx;
     size_t wbase = ((size_t)blockIdx.x * kHistWaves + wave) * kTripPx;
-    const bool packed = I.stride == I.w;  // block-uniform
+    const bool packed = !STRIDED || I.stride == I.w;  // block-uniform
     // the first trip's loads are issued before the LDS histogram is cleared: the clear (and the barrier
     // behind it) then runs in the shadow of the first memory round trip instead of in front of it
     u32x4 ld[kChunks];
@@ -337,11 +339,16 @@ hipError_t launch_median_batch(int k, const MedianView *views, uint32_t *const *
     }
     B.zero_ptr = scratch_dev + (size_t)((state->phase + 1) & 1) * half;
     B.zero_words = state->prev_words;
+    bool strided = false;
+    for (int i = 0; i < k; ++i) strided |= B.img[i].stride != B.img[i].w;
+    const dim3 grid(grid_x, (unsigned)k), block(64 * kHistWaves);
     if (two_launches) {
-        hipLaunchKernelGGL(median_kernel<false>, dim3(grid_x, (unsigned)k), dim3(64 * kHistWaves), 0, stream, B);
-        hipLaunchKernelGGL(median_select_kernel, dim3((unsigned)k), dim3(64 * kHistWaves), 0, stream, B);
+        if (strided) hipLaunchKernelGGL((median_kernel<false, true>), grid, block, 0, stream, B);
+        else hipLaunchKernelGGL((median_kernel<false, false>), grid, block, 0, stream, B);
+        hipLaunchKernelGGL(median_select_kernel, dim3((unsigned)k), block, 0, stream, B);
     } else {
-        hipLaunchKernelGGL(median_kernel<true>, dim3(grid_x, (unsigned)k), dim3(64 * kHistWaves), 0, stream, B);
+        if (strided) hipLaunchKernelGGL((median_kernel<true, true>), grid, block, 0, stream, B);
+        else hipLaunchKernelGGL((median_kernel<true, false>), grid, block, 0, stream, B);
     }
     const hipError_t e = hipGetLastError();
     if (e == hipSuccess) {
