@@ -966,6 +966,24 @@ def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_
                 t_mine, _ = _median_time(lambda: composite(c1_bg, c1_objs, q), 1.0, 300)
                 t_pil, _ = _median_time(lambda: _pillow_composite(c1_bg, c1_pil, q), 1.0, 300)
                 c1[key] = {"this_package_us": round(t_mine * 1e6, 1), "pillow_us": round(t_pil * 1e6, 1)}
+            # where the identity-scale call's time goes (stages timed on their own; profiles/r03_c1_breakdown.json has more)
+            from image_transformation_amd import _pilmem as _pm
+            from image_transformation_amd import compositor as _C
+            c1_rows = _C.coerce_placements(c1_objs, c1_pl)
+            c1_atlas = c1_objs.atlas()
+            tab = _pm.row_table(c1_bg)
+            colour = c1_bg.getpixel((0, 0))
+
+            def _enq_wait():
+                p = _C._composite_one(c1_atlas, SolidCanvas(c1_size, colour), c1_rows, 0)
+                _native.check(_native.lib().mic_download_wait(c1_atlas.ctx.handle, p.ticket))
+            c1["breakdown_us"] = {
+                "coerce_placements": round(_median_time(lambda: _C.coerce_placements(c1_objs, c1_pl), 0.2, 2000)[0] * 1e6, 1),
+                "row_table_and_3_getpixel": round(_median_time(lambda: (_pm.row_table(c1_bg), c1_bg.getpixel((0, 0)), c1_bg.getpixel((491, 491)), c1_bg.getpixel((246, 246))), 0.2, 2000)[0] * 1e6, 1),
+                "exact_solid_scan_of_the_background_(overlaps_the_gpu)": round(_median_time(lambda: _C._rows_solid(tab[0], 492, 492, colour), 0.2, 2000)[0] * 1e6, 1) if tab else None,
+                "enqueue_composite_and_download_then_wait_(no_scan)": round(_median_time(_enq_wait, 0.3, 2000)[0] * 1e6, 1),
+                "device_only_enqueue": round(_median_time(lambda: _C._composite_one(c1_atlas, SolidCanvas(c1_size, colour), c1_rows, 0, download=False), 0.2, 2000)[0] * 1e6, 1),
+                "pcie_floor_us_for_0.97_MB_at_55_GBps": 17.6}
             c1["note"] = "composite(PIL bg, load_object_images(results.json), placements) -> PIL on the squarespace bundle, 492x492 / 4 objects, median wall time"
             result["c1_bundle_dropin"] = c1
         except (OSError, StopIteration, KeyError) as exc:

@@ -50,6 +50,37 @@ def _workers() -> concurrent.futures.ThreadPoolExecutor:
     return _pool
 
 
+_good_layout: Optional[int] = None  # index into _LAYOUTS that row_runs() has validated in this process
+
+
+def row_table(img: Image.Image) -> Optional[Tuple[int, int, int]]:
+    """(address of Pillow's row-pointer table, W, H) of an RGBA image -- the cheap form of row_runs() for hot calls:
+    once row_runs() has proven a struct layout in this process (field by field and against getpixel), later images
+    only have their size fields checked against what the Python object reports (a handful of ctypes reads)."""
+    global _good_layout
+    try:
+        if img.mode != "RGBA":
+            return None
+        if _good_layout is None and row_runs(img) is None:
+            return None
+        img.load()
+        W, H = img.size
+        if W <= 0 or H <= 0 or _good_layout is None:
+            return None
+        cap = img.im.ptr
+        base = _get_ptr(cap, _get_name(cap))
+        if not base:
+            return None
+        o_bands, o_x, o_y, o_image, o_px, o_line = _LAYOUTS[_good_layout]
+        head = (ctypes.c_int32 * 24).from_address(base)
+        if (head[o_bands >> 2], head[o_x >> 2], head[o_y >> 2], head[o_px >> 2], head[o_line >> 2]) != (4, W, H, 4, 4 * W):
+            return None
+        table = ctypes.c_uint64.from_address(base + o_image).value
+        return (table, W, H) if table else None
+    except Exception:
+        return None
+
+
 def row_runs(img: Image.Image) -> Optional[List[Tuple[int, int]]]:
     """RGBA image -> [(address, bytes)] of maximal runs of rows that are contiguous in memory, in row
     order (a 4K image: three 16 MB blocks), or None if the image's memory cannot be located safely."""
@@ -65,7 +96,8 @@ def row_runs(img: Image.Image) -> Optional[List[Tuple[int, int]]]:
         if not base:
             return None
         head = np.frombuffer((ctypes.c_uint8 * 96).from_address(base), np.uint8)
-        for o_bands, o_x, o_y, o_image, o_px, o_line in _LAYOUTS:
+        global _good_layout
+        for li, (o_bands, o_x, o_y, o_image, o_px, o_line) in enumerate(_LAYOUTS):
             f = lambda o: int(head[o:o + 4].view(np.int32)[0])  # noqa: E731
             if (f(o_bands), f(o_x), f(o_y), f(o_px), f(o_line)) != (4, W, H, 4, 4 * W):
                 continue
@@ -80,6 +112,7 @@ def row_runs(img: Image.Image) -> Optional[List[Tuple[int, int]]]:
             last = tuple(np.frombuffer((ctypes.c_uint8 * 4).from_address(int(rows[-1]) + 4 * (W - 1)), np.uint8).tolist())
             if first != tuple(img.getpixel((0, 0))) or last != tuple(img.getpixel((W - 1, H - 1))):
                 continue
+            _good_layout = li
             line = 4 * W
             brk = np.nonzero(np.diff(rows) != line)[0] + 1
             starts = np.concatenate([[0], brk])

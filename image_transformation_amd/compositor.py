@@ -689,6 +689,156 @@ def composite_device(atlas: Atlas, canvases: Sequence[Union[SolidCanvas, Any]],
     return list(outs)
 
 
+_tls = threading.local()
+_raw_stream = None
+_DIRECT_HOST_MAX = int(os.environ.get("MIC_DIRECT_HOST_MAX", str(2 << 20)))  # bytes; 0: always device canvas + copy
+
+
+def _stream_of(ctx: _native.Context) -> int:
+    """torch's current stream on the context's device as a raw hipStream_t (the private accessor when this torch has
+    it: a tenth of the cost of torch.cuda.current_stream().cuda_stream)."""
+    global _raw_stream
+    if _raw_stream is None:
+        fn = getattr(_torch()._C, "_cuda_getCurrentRawStream", None)
+        _raw_stream = fn if fn is not None else False
+    return int(_raw_stream(ctx.device)) if _raw_stream else ctx.stream_ptr()
+
+
+class _PendingDownload:
+    __slots__ = ("ctx", "ticket", "pin", "size")
+
+    def __init__(self, ctx, ticket, pin, size):
+        self.ctx, self.ticket, self.pin, self.size = ctx, ticket, pin, size
+
+    def image(self) -> Image.Image:
+        _native.check(_native.lib().mic_download_wait(self.ctx.handle, self.ticket))
+        w, h = self.size
+        if _RESULT_COPY:
+            im = Image.new("RGBA", (w, h), None)
+            if _pilmem.copy_from(im, self.pin.data_ptr()):
+                return im
+            return Image.frombuffer("RGBA", (w, h), self.pin.numpy(), "raw", "RGBA", 0, 1).copy()
+        im = Image.frombuffer("RGBA", (w, h), self.pin.numpy(), "raw", "RGBA", 0, 1)
+        im.readonly = 0  # (see _to_pil: the buffer is the image's own)
+        return im
+
+
+def _composite_one(atlas: Atlas, canvas, rows, filter: int, download: bool = True):
+    """ONE canvas through mic_composite_batch with everything the call needs kept per thread between calls: the
+    ctypes job / placement arrays, the device output canvas of that size (the result leaves as a PIL image, the device
+    copy is scratch).  download=True: the device -> pinned-host copy is enqueued behind the kernel and a
+    _PendingDownload is returned (its .image() waits for that copy's own event, not for the stream); otherwise the
+    device tensor.  The reference-sized call (492 x 492, 4 cutouts) spends more time in Python than on the GPU:
+    profiles/r03_c1_breakdown.json."""
+    torch = _torch()
+    ctx = atlas.ctx
+    n = len(rows)
+    cache = _tls.__dict__.setdefault("one", {})
+    cap = 8
+    while cap < n:
+        cap *= 2
+    ent = cache.get(cap)
+    if ent is None:
+        parr = (Placement * cap)()
+        jobs = (Job * 1)()
+        jobs[0].placements = ctypes.cast(parr, ctypes.POINTER(Placement))
+        ent = cache[cap] = (jobs, parr, (_P * 1)())
+    jobs, parr, atl = ent
+    for i, (oid, x1, y1, x2, y2) in enumerate(rows):
+        if not (_I32_MIN <= x1 <= _I32_MAX and _I32_MIN <= y1 <= _I32_MAX and
+                _I32_MIN <= x2 <= _I32_MAX and _I32_MIN <= y2 <= _I32_MAX and _I32_MIN <= oid <= _I32_MAX):
+            raise OverflowError("placement coordinates do not fit 32 bits")
+        p = parr[i]
+        p.atlas = 0
+        p.object_id = oid
+        b = p.box
+        b[0], b[1], b[2], b[3] = x1, y1, x2, y2
+    j = jobs[0]
+    keep = None
+    if isinstance(canvas, SolidCanvas):
+        W, H = canvas.size
+        j.bg_dev = None
+        r = canvas.rgba
+        c = j.bg_rgba
+        c[0], c[1], c[2], c[3] = r[0], r[1], r[2], r[3]
+    else:
+        if canvas.dtype != torch.uint8 or canvas.dim() != 3 or canvas.shape[2] != 4 or not canvas.is_contiguous():
+            raise ValueError("device canvas must be a contiguous uint8 (H, W, 4) tensor")
+        if canvas.device != ctx.torch_device:
+            raise ValueError("canvas lives on another device than the atlas")
+        H, W = int(canvas.shape[0]), int(canvas.shape[1])
+        j.bg_dev = canvas.data_ptr()
+        keep = canvas
+    j.width, j.height, j.n_placements = W, H, n
+    nbytes = H * W * 4
+    # A small canvas that only leaves as a PIL image is written by the kernel STRAIGHT into the pinned host buffer the
+    # image will show (page-locked memory is device-visible at the same address): the copy engine's start-up costs
+    # more than the 0.97 MB of a 492 x 492 canvas takes over PCIe.  Big canvases keep the device canvas + DMA copy.
+    direct = download and nbytes <= _DIRECT_HOST_MAX
+    pin = _pinned(nbytes) if download else None
+    out = None
+    if not direct:
+        outs = _tls.__dict__.setdefault("outs", {})
+        key = (ctx.device, W, H)
+        out = outs.get(key) if download else None
+        if out is None:
+            out = torch.empty((H, W, 4), dtype=torch.uint8, device=ctx.torch_device)
+            if download:
+                if len(outs) >= 4:
+                    outs.pop(next(iter(outs)))
+                outs[key] = out
+    j.out_dev = pin.data_ptr() if direct else out.data_ptr()
+    atl[0] = atlas.handle
+    atlas.wait_ready()
+    stream = _stream_of(ctx)
+    lib = _native.lib()
+    with _device_guard(ctx):
+        _native.check(lib.mic_composite_batch(ctx.handle, 1, atl, 1, jobs, filter, _P(stream)))
+        del keep
+        if not download:
+            return out
+        ticket = ctypes.c_int32()
+        _native.check(lib.mic_download(ctx.handle, None if direct else _P(out.data_ptr()), _P(pin.data_ptr()),
+                                       0 if direct else nbytes, _P(stream), ctypes.byref(ticket)))
+    return _PendingDownload(ctx, ticket.value, pin, (W, H))
+
+
+def _rows_solid(table: int, W: int, H: int, rgba) -> bool:
+    """Every pixel of the host image behind Pillow's row table == rgba?  (mic_host_rows_solid; big images on the
+    4 copy threads: the C call releases the GIL)"""
+    lib = _native.lib()
+    col = (ctypes.c_uint8 * 4)(*rgba)
+
+    def part(y0, y1):
+        ok = ctypes.c_int()
+        _native.check(lib.mic_host_rows_solid(_P(table), W, y0, y1, col, ctypes.byref(ok)))
+        return ok.value == 1
+
+    if W * H * 4 < (4 << 20):
+        return part(0, H)
+    cuts = [H * k // 4 for k in range(5)]
+    return all(_pilmem._workers().map(lambda k: part(cuts[k], cuts[k + 1]), range(4)))
+
+
+def _composite_pil_background(atlas: Atlas, background_img: Image.Image, rows, filter: int) -> Image.Image:
+    """composite() / render() onto a PIL background.  The pipeline's backgrounds are fill_solid() canvases re-opened
+    from canvas.png (macro_placement_test.py:1510): one colour, which the kernel synthesises instead of reading an
+    uploaded image.  Whether the image IS one colour takes a full scan (exactness) -- as long as the GPU work itself
+    at the reference's size -- so the call speculates: when the first and the last pixel agree, the composite over
+    that colour and its download are enqueued FIRST and the scan runs while the GPU works; the rare image that then
+    turns out not to be solid is uploaded and composited again."""
+    tab = _pilmem.row_table(background_img)
+    if tab is not None:
+        table, W, H = tab
+        first = background_img.getpixel((0, 0))
+        if background_img.getpixel((W - 1, H - 1)) == first and background_img.getpixel((W // 2, H // 2)) == first:
+            pending = _composite_one(atlas, SolidCanvas((W, H), first), rows, filter)
+            if _rows_solid(table, W, H, first):
+                return pending.image()
+            _native.check(_native.lib().mic_download_wait(pending.ctx.handle, pending.ticket))  # (discarded)
+    return _composite_one(atlas, _upload(background_img, atlas.ctx), rows, filter).image()
+
+
 def composite(background_img: Image.Image, object_images: Mapping[int, Image.Image],
               placements: List[Dict], *, filter: int = LANCZOS) -> Image.Image:
     """Drop-in for the reference's composite() (compositor.py:6-22).
@@ -700,13 +850,9 @@ def composite(background_img: Image.Image, object_images: Mapping[int, Image.Ima
         return background_img.copy()  # compositor.py:11 with an empty loop
     if background_img.mode != "RGBA":
         raise ValueError("image has wrong mode")  # what Pillow's core.alpha_composite raises
-    atlas = _as_atlas(object_images)
-    # The pipeline's backgrounds are fill_solid() canvases re-opened from canvas.png
-    # (macro_placement_test.py:1510): one colour.  Then nothing is uploaded, the kernel synthesises it.
-    solid = _pilmem.solid_colour(background_img)
-    canvas = SolidCanvas(background_img.size, solid) if solid is not None else _upload(background_img, atlas.ctx)
-    out = composite_device(atlas, [canvas], [rows], filter=filter)[0]
-    return _to_pil(out)
+    if filter not in _FILTERS:
+        raise ValueError(f"unknown filter {filter}")
+    return _composite_pil_background(_as_atlas(object_images), background_img, rows, filter)
 
 
 def _layout_rows(layout_json: Any, images: Mapping[int, Any], atlas: "Atlas", size: Tuple[int, int]):
@@ -785,6 +931,10 @@ def render(layout_json: Any, objects: Mapping[int, Any], canvas: Any, *, filter:
             return canvas.copy()
         if canvas.mode != "RGBA":
             raise ValueError("image has wrong mode")
+        if filter not in _FILTERS:
+            raise ValueError(f"unknown filter {filter}")
+        if not as_tensor:
+            return _composite_pil_background(atlas, canvas, rows, filter)
         solid = _pilmem.solid_colour(canvas)
         canvas = SolidCanvas(canvas.size, solid) if solid is not None else _upload(canvas, atlas.ctx)
     out = composite_device(atlas, [canvas], [rows], filter=filter)[0]

@@ -28,6 +28,8 @@
 // path; any partial alpha in the wave sends it through the full formula.
 //
 // HBM-bound by construction: MFMA is not used (there is no contraction to feed it).
+#include <cstring>
+
 #include "mic_internal.h"
 
 namespace mic {
@@ -200,19 +202,28 @@ __device__ __forceinline__ void edge_page(const Job &job, const Layer *jl, int64
 #ifndef MIC_HOT_WAVES
 #define MIC_HOT_WAVES 7
 #endif
-// ONE: the launch holds a single job, handed over BY VALUE in the kernel arguments (scalar loads from the
-// kernarg segment) instead of through the device job table: a wave's first memory round trip -- of the three
-// dependent ones it makes: job, layer records, cutout pixels -- disappears, and so does the table upload.
-// That is the reference's own call shape: one composite() per call (compositor.py:6-22).
-template <bool ALIGNED, bool SOLID, bool ONE>
+// MODE (where a wave finds its job and layer records):
+//   kFromTables  batches: job blockIdx.y of the device job table, layer records in the device layer table;
+//   kJobInArgs   ONE job, handed over BY VALUE in the kernel arguments (scalar loads from the kernarg segment) instead
+//                of through the device job table: a wave's first memory round trip -- of the three dependent ones it
+//                makes: job, layer records, cutout pixels -- disappears, and so does the table upload.  That is the
+//                reference's own call shape: one composite() per call (compositor.py:6-22);
+//   kAllInArgs   ... and its layer records too (round 3), when there are at most kPackLayers of them (2 KiB of the
+//                4 KiB argument segment): nothing at all is uploaded for such a call -- a one-shot composite() is the
+//                launch alone -- and lane l reads record l straight from the argument segment.
+enum : int { kFromTables = 0, kJobInArgs = 1, kAllInArgs = 2 };
+struct LayerPack {
+    Layer l[kPackLayers];
+};
+template <bool ALIGNED, bool SOLID, int MODE>
 __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6 : 4)) void composite_kernel(
-    const Job *__restrict__ jobs, const Layer *__restrict__ layers, const Job one) {
-    const Job job = ONE ? one : jobs[blockIdx.y];
+    const Job *__restrict__ jobs, const Layer *__restrict__ layers, const Job one, const LayerPack pack) {
+    const Job job = MODE != kFromTables ? one : jobs[blockIdx.y];
     if ((int)blockIdx.x >= job.n_pages) return;
     const int lane = threadIdx.x;
     const int W = job.W;
     const int64_t n_px = (int64_t)job.W * job.H;
-    const Layer *jl = layers + job.layer_begin;
+    const Layer *jl = MODE == kAllInArgs ? pack.l : layers + job.layer_begin;
 
     const int64_t qp = (int64_t)blockIdx.x * kPagePx - job.px_shift;
     // pages that lie wholly inside the canvas: all but the first/last of a page-misaligned canvas
@@ -451,37 +462,52 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
 // Jobs arrive sorted by class: [0, n0) aligned+solid, [n0, n1) unaligned+solid, [n1, n2) aligned with
 // a background image / translucent colour, [n2, n_jobs) neither.  single != nullptr: the launch's only job,
 // passed in the kernel arguments (jobs_dev is not read).
+// The argument block of every launch carries a LayerPack (2 KiB copied into the kernarg ring by the runtime: a few
+// dozen nanoseconds); only kAllInArgs launches read it.  One per calling thread: contexts are driven concurrently.
+static thread_local LayerPack g_pack;
+
 hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_jobs, const int class_end[3],
-                            int pitch, const Job *single, hipStream_t stream) {
+                            int pitch, const Job *single, const Layer *single_layers_host, hipStream_t stream) {
     if (n_jobs <= 0 || pitch <= 0) return hipSuccess;
     // grid.x (= pitch) is a multiple of 8 so that (linear workgroup id) mod 8 == (page index) mod 8
     // for every job of the launch: the XCD <-> page residue pairing survives the 2-D grid.
     const int b[5] = {0, class_end[0], class_end[1], class_end[2], n_jobs};
     if (single && n_jobs == 1) {
         const dim3 grid((unsigned)pitch, 1u);
-        if (b[1] > b[0])
-            hipLaunchKernelGGL((composite_kernel<true, true, true>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single);
-        else if (b[2] > b[1])
-            hipLaunchKernelGGL((composite_kernel<false, true, true>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single);
-        else if (b[3] > b[2])
-            hipLaunchKernelGGL((composite_kernel<true, false, true>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single);
-        else
-            hipLaunchKernelGGL((composite_kernel<false, false, true>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single);
+        const int cls = b[1] > b[0] ? 0 : b[2] > b[1] ? 1 : b[3] > b[2] ? 2 : 3;
+        if (single_layers_host && single->layer_count <= kPackLayers) {
+            Job one = *single;
+            if (one.layer_count > 0) memcpy(g_pack.l, single_layers_host + one.layer_begin, sizeof(Layer) * (size_t)one.layer_count);
+            one.layer_begin = 0;
+            switch (cls) {
+                case 0: hipLaunchKernelGGL((composite_kernel<true, true, kAllInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+                case 1: hipLaunchKernelGGL((composite_kernel<false, true, kAllInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+                case 2: hipLaunchKernelGGL((composite_kernel<true, false, kAllInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+                default: hipLaunchKernelGGL((composite_kernel<false, false, kAllInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+            }
+            return hipGetLastError();
+        }
+        switch (cls) {
+            case 0: hipLaunchKernelGGL((composite_kernel<true, true, kJobInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
+            case 1: hipLaunchKernelGGL((composite_kernel<false, true, kJobInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
+            case 2: hipLaunchKernelGGL((composite_kernel<true, false, kJobInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
+            default: hipLaunchKernelGGL((composite_kernel<false, false, kJobInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
+        }
         return hipGetLastError();
     }
     const Job none{};
     if (b[1] > b[0])
-        hipLaunchKernelGGL((composite_kernel<true, true, false>), dim3((unsigned)pitch, (unsigned)(b[1] - b[0])), dim3(64),
-                           0, stream, jobs_dev + b[0], layers_dev, none);
+        hipLaunchKernelGGL((composite_kernel<true, true, kFromTables>), dim3((unsigned)pitch, (unsigned)(b[1] - b[0])), dim3(64),
+                           0, stream, jobs_dev + b[0], layers_dev, none, g_pack);
     if (b[2] > b[1])
-        hipLaunchKernelGGL((composite_kernel<false, true, false>), dim3((unsigned)pitch, (unsigned)(b[2] - b[1])), dim3(64),
-                           0, stream, jobs_dev + b[1], layers_dev, none);
+        hipLaunchKernelGGL((composite_kernel<false, true, kFromTables>), dim3((unsigned)pitch, (unsigned)(b[2] - b[1])), dim3(64),
+                           0, stream, jobs_dev + b[1], layers_dev, none, g_pack);
     if (b[3] > b[2])
-        hipLaunchKernelGGL((composite_kernel<true, false, false>), dim3((unsigned)pitch, (unsigned)(b[3] - b[2])), dim3(64),
-                           0, stream, jobs_dev + b[2], layers_dev, none);
+        hipLaunchKernelGGL((composite_kernel<true, false, kFromTables>), dim3((unsigned)pitch, (unsigned)(b[3] - b[2])), dim3(64),
+                           0, stream, jobs_dev + b[2], layers_dev, none, g_pack);
     if (b[4] > b[3])
-        hipLaunchKernelGGL((composite_kernel<false, false, false>), dim3((unsigned)pitch, (unsigned)(b[4] - b[3])), dim3(64),
-                           0, stream, jobs_dev + b[3], layers_dev, none);
+        hipLaunchKernelGGL((composite_kernel<false, false, kFromTables>), dim3((unsigned)pitch, (unsigned)(b[4] - b[3])), dim3(64),
+                           0, stream, jobs_dev + b[3], layers_dev, none, g_pack);
     return hipGetLastError();
 }
 

@@ -52,7 +52,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *mic_last_error(void) { return g_err; }
-extern "C" int mic_version(void) { return (1 << 16) | 7; }  // 1.7: + mic_median_rgb_batch, 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
+extern "C" int mic_version(void) { return (1 << 16) | 7; }  // 1.7: + mic_median_rgb_batch, mic_host_rows_solid, mic_download(_wait); 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
 
 // ------------------------------------------------------------------------------------ blob layout
 namespace {
@@ -174,10 +174,17 @@ struct mic_ctx {
     int64_t march_min_units = 512;
     uint32_t *median_scratch = nullptr;  // device: two sets of histogram slots (a double buffer) + kMedianMaxBatch result words
     MedianState median_state;            // which half the next call works in, what the previous one left to clear
+    bool layer_args = true;              // MIC_LAYER_ARGS=0: single-canvas launches read their layer records from the device table
     bool median_two_launches = false;    // MIC_MEDIAN_TWO_LAUNCHES=1: histogram kernel + select kernel (measurement aid)
     uint32_t *gradient_table = nullptr;  // device: fill_gradient's per-position colours (allocated on first use)
     uint32_t *median_host = nullptr;     // pinned
     hipStream_t last_stream = nullptr;
+    // mic_download: a ring of events, one per copy in flight (ticket = ring index); an entry that comes round again
+    // while nobody has waited for it is waited for by the enqueuer before it is re-recorded
+    static constexpr int kDownloads = 16;
+    hipEvent_t dl_event[kDownloads] = {};
+    bool dl_pending[kDownloads] = {};
+    int dl_next = 0;
     mic_stats stats{};
     uint64_t next_atlas_uid = 1;
     // optional event brackets around the kernels (mic_profile_begin/end)
@@ -241,6 +248,7 @@ extern "C" int mic_create(int device, mic_ctx **out) {
             return fail(MIC_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
         }
     }
+    if (const char *la = getenv("MIC_LAYER_ARGS")) ctx->layer_args = atoi(la) != 0;
     if (const char *tl = getenv("MIC_MEDIAN_TWO_LAUNCHES")) ctx->median_two_launches = atoi(tl) != 0;
     e = hipMalloc(&ctx->median_scratch, (kMedianScratchWords + 64) * sizeof(uint32_t));
     // zeroed once: every median call clears the half of the double buffer the call before it used
@@ -269,6 +277,8 @@ extern "C" int mic_destroy(mic_ctx *ctx) {
     }
     ctx->frags.clear();  // buffers free themselves (plans still alive keep theirs)
     for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->dl_event)
+        if (ev) (void)hipEventDestroy(ev);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->median_scratch) (void)hipFree(ctx->median_scratch);
     if (ctx->gradient_table) (void)hipFree(ctx->gradient_table);
@@ -1078,6 +1088,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     // A single job travels in the kernel arguments (launch_composite): no device job table, no upload, no
     // table cache -- a persistent single-canvas plan's run is the launch alone.
     const bool one = n_jobs == 1;
+    const bool pack_layers = one && ctx->layer_args && P->layers.size() <= (size_t)kPackLayers;
     mic_plan::JobTable *slot_tab = nullptr;
     if (P->persistent && !one) {
         ++P->run_counter;
@@ -1165,6 +1176,11 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         Slot *slot = nullptr;
         if (P->persistent && one) {
             dp = static_cast<char *>(P->tables_dev);
+        } else if (pack_layers && P->pt.fused.empty() && P->pt.tiles.empty() && P->pt.h.empty() && P->pt.v.empty()) {
+            // one canvas, <= 64 identity-scale layers (the reference's own call, compositor.py:6-22 from the Flex
+            // pipeline): job AND layer records ride in the kernel arguments -- nothing is staged, nothing uploaded
+            static char nothing[64];
+            dp = nothing;  // (no table is read through it: every launcher below sees a count of 0)
         } else {
         if (int rc = acquire_slot(ctx, upload, &slot)) return rc;
         char *hp = static_cast<char *>(slot->host);
@@ -1213,7 +1229,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
                               P->pt.max_v_out_w, P->pt.max_v_out_h, stream));
     if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
     HIP_TRY(launch_composite(jobs_dev, reinterpret_cast<const Layer *>(dp + P->off_layers), n_jobs, class_end, pitch,
-                             one ? &P->ordered[0] : nullptr, stream));
+                             one ? &P->ordered[0] : nullptr, pack_layers ? P->layers.data() : nullptr, stream));
     if (prof) {
         HIP_TRY(hipEventRecord(pe[2], stream));
         ++ctx->prof_calls;
@@ -1612,6 +1628,70 @@ extern "C" int mic_draw_rect_outlines(mic_ctx *ctx, void *out_dev, int32_t width
     HIP_TRY(hipEventRecord(slot->ev, stream));
     slot->pending = true;
     HIP_TRY(launch_rect_outlines(out_dev, width, height, static_cast<const OutlineRect *>(slot->dev), n, w, stream));
+    return MIC_OK;
+}
+
+// ------------------------------------------------------------------------------------ PIL-level drop-in helpers
+extern "C" int mic_host_rows_solid(const void *const *rows_host, int32_t width, int32_t y0, int32_t y1,
+                                   const uint8_t rgba[4], int *is_solid) {
+    if (!rows_host || !rgba || !is_solid || width <= 0 || y0 < 0 || y1 < y0)
+        return fail(MIC_ERR_INVALID, "mic_host_rows_solid: bad arguments");
+    uint32_t c;
+    memcpy(&c, rgba, 4);
+    const uint64_t cc = (uint64_t)c | ((uint64_t)c << 32);
+    *is_solid = 0;
+    for (int32_t y = y0; y < y1; ++y) {
+        const uint8_t *row = static_cast<const uint8_t *>(rows_host[y]);
+        if (!row) return fail(MIC_ERR_INVALID, "mic_host_rows_solid: row %d is null", y);
+        int32_t x = 0;
+        uint64_t diff = 0;  // OR of (pixel pair ^ colour): branch-free inner loop, one test per 64 pixels
+        for (; x + 64 <= width; x += 64) {
+            for (int k = 0; k < 32; ++k) {
+                uint64_t v;
+                memcpy(&v, row + (size_t)(x + 2 * k) * 4, 8);
+                diff |= v ^ cc;
+            }
+            if (diff) return MIC_OK;
+        }
+        for (; x < width; ++x) {
+            uint32_t v;
+            memcpy(&v, row + (size_t)x * 4, 4);
+            diff |= v ^ c;
+        }
+        if (diff) return MIC_OK;
+    }
+    *is_solid = 1;
+    return MIC_OK;
+}
+
+extern "C" int mic_download(mic_ctx *ctx, const void *src_dev, void *dst_host, size_t bytes, void *stream_v,
+                            int32_t *ticket) {
+    CTX_ENTER(ctx);
+    if (!ticket || (bytes > 0 && (!src_dev || !dst_host))) return fail(MIC_ERR_INVALID, "mic_download: null pointer");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    const int t = ctx->dl_next;
+    ctx->dl_next = (t + 1) % mic_ctx::kDownloads;
+    if (!ctx->dl_event[t]) HIP_TRY(hipEventCreateWithFlags(&ctx->dl_event[t], hipEventDisableTiming));
+    if (ctx->dl_pending[t]) HIP_TRY(hipEventSynchronize(ctx->dl_event[t]));  // 16 copies later and still not waited for
+    if (bytes > 0) HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipEventRecord(ctx->dl_event[t], stream));
+    ctx->dl_pending[t] = true;
+    *ticket = t;
+    return MIC_OK;
+}
+
+extern "C" int mic_download_wait(mic_ctx *ctx, int32_t ticket) {
+    if (!ctx || ticket < 0 || ticket >= mic_ctx::kDownloads) return fail(MIC_ERR_INVALID, "mic_download_wait: bad arguments");
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+        if (!ctx->dl_pending[ticket]) return MIC_OK;
+        ev = ctx->dl_event[ticket];
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ev));  // (not under the lock: other threads keep enqueueing)
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    ctx->dl_pending[ticket] = false;
     return MIC_OK;
 }
 

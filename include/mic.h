@@ -204,6 +204,21 @@ int mic_contact_sheet(mic_ctx *ctx, mic_atlas *atlas, int32_t n, const int32_t *
                       int32_t thumb_h, int32_t cols, int32_t label_h, int32_t n_strips,
                       const mic_label_strip *strips, void *out_dev, void *stream);
 
+/* ---- host-side helpers of the PIL-level drop-in (compositor.py:6-22 called with PIL images) ---------------
+ * mic_host_rows_solid: is every pixel of rows [y0, y1) of a host RGBA image equal to rgba?  rows_host: one pointer
+ * per row (Pillow's own row table), width pixels each.  *is_solid receives 1 or 0.  Exact: every byte is compared.
+ * The reference's backgrounds are fill_solid() canvases re-opened from canvas.png every iteration
+ * (macro_placement_test.py:1510); a one-colour background is synthesised in-kernel instead of uploaded.      */
+int mic_host_rows_solid(const void *const *rows_host, int32_t width, int32_t y0, int32_t y1, const uint8_t rgba[4],
+                        int *is_solid);
+/* mic_download: enqueue a device -> pinned-host copy on `stream` and mark its end with an event of its own;
+ * *ticket names it.  mic_download_wait(ticket) blocks the calling thread until THAT copy has landed (an event wait,
+ * not a stream drain; other threads keep enqueueing meanwhile).  A ticket is waited for at most once.
+ * bytes == 0: no copy, only the mark -- for a kernel that wrote its canvas straight into pinned host memory (out_dev
+ * of a job may be the device-visible address of such a buffer: small canvases skip the copy engine that way).    */
+int mic_download(mic_ctx *ctx, const void *src_dev, void *dst_host, size_t bytes, void *stream, int32_t *ticket);
+int mic_download_wait(mic_ctx *ctx, int32_t ticket);
+
 /* ---- PNG writer: replaces PIL's encoder behind the reference's artifact saves ---------------------
  * (`canvas_img.save(canvas_path)` macro_placement_test.py:1428-1430, `draft.save(...)` :1513 / :1699, the overlay
  * :1514 / :1700).  Host-only (no context, no device): RGBA8 rows in host memory -> an 8-bit RGBA, non-interlaced

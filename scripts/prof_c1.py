@@ -56,6 +56,29 @@ out["d2h_copy_plus_sync_us"] = med(d2h)
 out["frombuffer_us"] = med(lambda: Image.frombuffer("RGBA", (492, 492), pin.numpy(), "raw", "RGBA", 0, 1))
 out["to_pil_us"] = med(lambda: C._to_pil(dev_out))
 out["empty_sync_us"] = med(lambda: torch.cuda.current_stream().synchronize())
+# ---- the round-3 path: speculative solid background, per-thread cached job arrays, event-waited download
+tab = _pilmem.row_table(bg)
+out["r03_row_table_us"] = med(lambda: _pilmem.row_table(bg))
+out["r03_three_getpixel_us"] = med(lambda: (bg.getpixel((0, 0)), bg.getpixel((491, 491)), bg.getpixel((246, 246))))
+out["r03_rows_solid_scan_us"] = med(lambda: C._rows_solid(tab[0], 492, 492, (220, 238, 245, 255)))
+out["r03_stream_of_us"] = med(lambda: C._stream_of(ctx))
+def one_enqueue():
+    p = C._composite_one(atlas, canvas, rows, 0)
+    _native.check(_native.lib().mic_download_wait(ctx.handle, p.ticket))
+def one_enqueue_only():
+    return C._composite_one(atlas, canvas, rows, 0)
+t_both = med(one_enqueue)
+pend = []
+def enq():
+    pend.append(C._composite_one(atlas, canvas, rows, 0))
+    if len(pend) >= 8:
+        for q in pend:
+            _native.check(_native.lib().mic_download_wait(ctx.handle, q.ticket))
+        pend.clear()
+out["r03_composite_one_enqueue_plus_wait_us"] = t_both
+p0 = C._composite_one(atlas, canvas, rows, 0)
+out["r03_pending_image_us"] = med(lambda: p0.image())
+out["r03_device_only_composite_one_us"] = med(lambda: C._composite_one(atlas, canvas, rows, 0, download=False))
 print(json.dumps(out, indent=1))
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 with open(os.path.join(ROOT, "gpurun_out", "c1_breakdown.json"), "w") as f:

@@ -49,3 +49,42 @@ def test_solid_colour_is_exact(size):
         t.putpixel(xy, tuple(px))
         assert _pilmem.solid_colour(t) is None, xy
     assert _pilmem.solid_colour(Image.new("RGBA", size, (0, 0, 0, 0))) == (0, 0, 0, 0)
+
+
+def test_row_table_and_exact_solid_scan():
+    """row_table() (the cheap form used by the hot drop-in call) agrees with row_runs(); mic_host_rows_solid compares
+    every byte: one differing byte anywhere (first / last pixel, a middle row, an alpha byte) is found, row ranges work,
+    images in several memory blocks work."""
+    import ctypes
+    from image_transformation_amd import _native
+    lib = _native.lib()
+
+    def solid(im, rgba, y0=0, y1=None):
+        table, W, H = _pilmem.row_table(im)
+        ok = ctypes.c_int(7)
+        col = (ctypes.c_uint8 * 4)(*rgba)
+        assert lib.mic_host_rows_solid(ctypes.c_void_p(table), W, y0, H if y1 is None else y1, col, ctypes.byref(ok)) == 0
+        return ok.value
+
+    for size in ((492, 492), (3840, 2160), (1, 1), (63, 5), (64, 5), (65, 5), (129, 3)):
+        c = (220, 238, 245, 255)
+        im = Image.new("RGBA", size, c)
+        tab = _pilmem.row_table(im)
+        assert tab is not None and tab[1:] == size
+        runs = _pilmem.row_runs(im)
+        first_row = ctypes.c_uint64.from_address(tab[0]).value
+        assert first_row == runs[0][0]
+        assert solid(im, c) == 1 and solid(im, (220, 238, 245, 254)) == 0
+        W, H = size
+        for (x, y) in {(0, 0), (W - 1, H - 1), (W // 2, H // 2), (W - 1, 0), (0, H - 1)}:
+            for ch in range(4):
+                px = list(c)
+                px[ch] ^= 1
+                im.putpixel((x, y), tuple(px))
+                assert solid(im, c) == 0, (size, x, y, ch)
+                if H > 2 and 0 < y < H - 1:
+                    assert solid(im, c, 0, y) == 1 and solid(im, c, y + 1, H) == 1 and solid(im, c, y, y + 1) == 0
+                im.putpixel((x, y), c)
+        assert solid(im, c) == 1
+    assert _pilmem.row_table(Image.new("RGB", (4, 4))) is None
+    assert _pilmem.solid_colour(Image.new("RGBA", (300, 200), (1, 2, 3, 4))) == (1, 2, 3, 4)
