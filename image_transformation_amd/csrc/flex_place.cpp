@@ -33,6 +33,7 @@ struct JValue {
     enum Kind { Null, Bool, Int, Float, String, Array, Object } kind = Null;
     bool b = false;
     long long i = 0;
+    double d = 0.0;  // Float: the value Python's float() would hold (strtod is correctly rounded, like CPython's parser)
     std::string s;
     std::vector<JPtr> arr;
     std::vector<std::pair<std::string, JPtr>> obj;  // insertion order; duplicate keys: last wins on lookup
@@ -160,6 +161,8 @@ struct Parser {
         }
         if (is_float || p - s0 > 15) {
             v->kind = JValue::Float;
+            v->d = strtod(std::string(s0, p).c_str(), nullptr);
+            // (a 16+ digit integer lands here too: far outside every range accepted below)
         } else {
             v->kind = JValue::Int;
             v->i = strtoll(std::string(s0, p).c_str(), nullptr, 10);
@@ -175,12 +178,38 @@ struct Placer {
     const std::map<long long, std::pair<int, int>> &sizes;
     std::vector<int32_t> &ids, &boxes;
 
+    // int("12") / int(" -7 "): an optional sign and plain ASCII decimal digits between ASCII blanks.  Everything
+    // else int() accepts for a str (underscores, other Unicode digits and spaces) stays Python's business.
+    static long long int_of_string(const std::string &t) {
+        size_t a = 0, b = t.size();
+        while (a < b && (t[a] == ' ' || t[a] == '\t' || t[a] == '\n')) ++a;
+        while (b > a && (t[b - 1] == ' ' || t[b - 1] == '\t' || t[b - 1] == '\n')) --b;
+        size_t d = a;
+        if (d < b && (t[d] == '+' || t[d] == '-')) ++d;
+        if (d == b || b - d > 9) throw Unsupported{};
+        for (size_t k = d; k < b; ++k)
+            if (t[k] < '0' || t[k] > '9') throw Unsupported{};
+        return strtoll(t.substr(a, b - a).c_str(), nullptr, 10);
+    }
+    // int(node.get(key, dflt)) as the reference applies it to a container's gap_px / padding_px
+    // (macro_placement_test.py:661-662, :696-697): an int as it is, a float truncated toward zero, a bool as 0 / 1,
+    // a plain decimal string parsed; null / lists / objects raise TypeError there -> the Python placer's business.
     static long long int_field(const JValue &node, const char *key, long long dflt) {
         const JValue *v = node.get(key);
         if (!v) return dflt;
-        if (v->kind != JValue::Int) throw Unsupported{};  // floats, strings, bools, null: Python's int() rules
-        if (v->i < -(1 << 24) || v->i > (1 << 24)) throw Unsupported{};
-        return v->i;
+        long long r;
+        switch (v->kind) {
+            case JValue::Int: r = v->i; break;
+            case JValue::Bool: r = v->b ? 1 : 0; break;
+            case JValue::Float:
+                if (!(v->d > -16777216.0 && v->d < 16777216.0)) throw Unsupported{};  // (also NaN)
+                r = (long long)v->d;  // C++ truncates toward zero, like int(float)
+                break;
+            case JValue::String: r = int_of_string(v->s); break;
+            default: throw Unsupported{};
+        }
+        if (r < -(1 << 24) || r > (1 << 24)) throw Unsupported{};
+        return r;
     }
     static std::string str_field(const JValue &node, const char *key, const char *dflt) {
         const JValue *v = node.get(key);
@@ -275,18 +304,7 @@ struct Placer {
     }
     long long object_id(const JValue &node) const {
         const JValue *v = node.get("object_id");
-        if (v->kind == JValue::String) {  // int("3"): plain decimal digits only; anything fancier is Python's business
-            const std::string &t = v->s;
-            size_t a = 0, b = t.size();
-            while (a < b && (t[a] == ' ' || t[a] == '\t' || t[a] == '\n')) ++a;
-            while (b > a && (t[b - 1] == ' ' || t[b - 1] == '\t' || t[b - 1] == '\n')) --b;
-            size_t d = a;
-            if (d < b && (t[d] == '+' || t[d] == '-')) ++d;
-            if (d == b || b - d > 9) throw Unsupported{};
-            for (size_t k = d; k < b; ++k)
-                if (t[k] < '0' || t[k] > '9') throw Unsupported{};
-            return strtoll(t.substr(a, b - a).c_str(), nullptr, 10);
-        }
+        if (v->kind == JValue::String) return int_of_string(v->s);  // int("3")
         if (v->kind != JValue::Int) throw Unsupported{};  // int(3.7), int(True), None: Python's business
         return v->i;
     }

@@ -70,7 +70,7 @@ def test_native_placer_matches_reference_or_declines(flex_golden):
         # the JSON text form (a VLM reply) gives the same answer, whitespace and key order aside
         text = _json.dumps(case["layout"], indent=2, sort_keys=True)
         assert flex.native_boxes(text, sizes, tuple(case["canvas"])) == want, case["name"]
-    assert accepted >= 0.95 * (len(flex_golden["cases"]) + len(flex_golden["kat"])), accepted
+    assert accepted == len(flex_golden["cases"]) + len(flex_golden["kat"]), accepted  # round 3: every reference tree
     sq = {k: tuple(v) for k, v in cases.SQUARESPACE_SIZES.items()}
     for row in flex_golden["errors"]:  # every malformed object field is left to flex.py (which raises)
         node = dict({"object_id": 2}, **row["fields"])
@@ -80,6 +80,32 @@ def test_native_placer_matches_reference_or_declines(flex_golden):
     assert flex.native_boxes("{not json", sq, (492, 492)) is None
     assert flex.native_boxes({"placements": []}, sq, (492, 492)) is None
     assert flex.native_boxes('{"root": {"direction": "r\\u006fw", "children": []}}', sq, (9, 9)) is None
+
+
+def test_native_placer_int_coercion_of_container_fields():
+    """A container's gap_px / padding_px go through int() in the reference (macro_placement_test.py:661-662, :696-697):
+    floats truncate toward zero, bools are 0 / 1, plain decimal strings parse; the native placer mirrors exactly those
+    and leaves the rest of int()'s repertoire (and its TypeErrors) to flex.py.  Accepted forms must equal flex.py."""
+    sq = {k: tuple(v) for k, v in cases.SQUARESPACE_SIZES.items()}
+
+    def tree(**kw):
+        root = {"type": "flex", "direction": "row", "children": [{"object_id": 1}, {"object_id": "4"}, {"object_id": 3}]}
+        root.update(kw)
+        return {"root": root}
+
+    accepted = [3.9, -3.9, 0.5, -0.5, 1e2, "12", " +7 ", "-3", "007", True, False, 0, -5, 16777216]
+    for key in ("gap_px", "padding_px"):
+        for v in accepted:
+            layout = tree(**{key: v})
+            want = [(int(p["object_id"]), *p["box"]) for p in flex.layout_to_placements(layout, sq, (492, 492))]
+            assert flex.native_boxes(layout, sq, (492, 492)) == want, (key, v)
+            assert flex.native_boxes(json.dumps(layout), sq, (492, 492)) == want, (key, v)
+        for v in (None, "1_2", "\uff11\uff12", [1], {"a": 1}, 1e9, -1e30, "3.9", "", "+", "12345678901", 16777217):
+            assert flex.native_boxes(tree(**{key: v}), sq, (492, 492)) is None, (key, v)
+    # the equivalence int(3.9) == 3 etc. really is what flex.py (the reference's mirror) computes
+    a = flex.layout_to_placements(tree(gap_px=3.9), sq, (492, 492))
+    b = flex.layout_to_placements(tree(gap_px=3), sq, (492, 492))
+    assert [p["box"] for p in a] == [p["box"] for p in b]
 
 
 def test_layout_to_placements_forms(flex_golden):

@@ -77,6 +77,24 @@ def test_flex_parser_and_tables_under_asan_ubsan(binary, golden_dir):
               (b'{"root":{"children":[' + b'{"object_id":1},' * 5000 + b'{"object_id":2}]}}', sq, (492, 492)),
               (deep, sq, (492, 492)), (b'{"root":{"gap_px":99999999999999999999999,"children":[]}}', sq, (5, 5)),
               (b'{"root":{"padding_px":-0,"children":[{"object_id":"0004"}]}}', sq, (5, 5))]
+    # round 3: int() coercion of a container's gap_px / padding_px (floats, exponents, numeric strings, bools) -- the
+    # extremes of strtod / the double -> integer cast and of the string parser, then mutated like everything else
+    coerce = [b"3.9", b"-3.9", b"1e2", b"1e308", b"-1e308", b"1e999", b"1e-999", b"0.0000000000000000001e19", b"16777215.99",
+              b"16777216.0", b"-16777216.5", b"9007199254740993", b"123456789012345678901234567890.5", b'"12"', b'" +7 "',
+              b'"-"', b'""', b'"   "', b'"+0000000001"', b'"1234567890"', b'"12\n"', b'"\t3"', b'"1_2"', b'"0x10"', b"true",
+              b"false", b"null", b"-0.0", b"2.5e-1", b"1E+2", b"1e+", b"1.", b".5", b"-", b"1e"]
+    extra = []
+    for v in coerce:
+        for key in (b"gap_px", b"padding_px"):
+            extra.append((b'{"root":{"type":"flex","direction":"column","' + key + b'":' + v +
+                          b',"children":[{"object_id":1},{"' + key + b'":' + v + b',"children":[{"object_id":"2"}]}]}}', sq, (492, 492)))
+    cases += extra
+    for _ in range(600):
+        text, sizes, canvas = extra[int(rng.integers(0, len(extra)))]
+        b = bytearray(text)
+        pos = int(rng.integers(0, len(b)))
+        b[pos:pos] = bytes([structural[int(rng.integers(0, len(structural)))]]) * int(rng.integers(1, 3))
+        cases.append((bytes(b), sizes, canvas))
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([binary], input=_pack(cases), capture_output=True, env=env, timeout=600)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
