@@ -71,6 +71,7 @@ SYMBOLS = {
     "mic_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(_P)]),
     "mic_destroy": (ctypes.c_int, [_P]),
     "mic_sync": (ctypes.c_int, [_P, _P]),
+    "mic_selftest": (ctypes.c_int, [_P, _P]),
     "mic_atlas_create": (ctypes.c_int, [_P, ctypes.c_int, _I32P, _I32P, _I32P, ctypes.POINTER(_P),
                                         ctypes.POINTER(_P)]),
     "mic_atlas_blob_size": (ctypes.c_int, [ctypes.c_int, _I32P, _I32P, ctypes.POINTER(ctypes.c_size_t)]),
@@ -214,6 +215,10 @@ class Context:
         check(lib().mic_profile_end(self.handle, _P(self.stream_ptr()), ctypes.byref(n), ctypes.byref(c),
                                     ctypes.byref(r)))
         return n.value, c.value, r.value
+
+    def selftest(self) -> None:
+        """Known-answer canary of the clip / pack helpers (mic_selftest); raises MicError on a mismatch."""
+        check(lib().mic_selftest(self.handle, _P(self.stream_ptr())))
 
     def sync(self) -> None:
         check(lib().mic_sync(self.handle, _P(self.stream_ptr())))

@@ -93,5 +93,40 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def check_isa(verbose: bool = False) -> None:
+    """Build-time canary of the v_ashr_pk_u8_i32 workaround (kernels_resample.hip: clip8), on the CPU: compile the
+    resample sources to gfx950 assembly and look at what the compiler made of them.  hipcc 7.2 fuses "shift, clamp to
+    0..255, pack" into v_ashr_pk_u8_i32 and then treats the untouched upper half of its destination as zero; clip8's
+    empty asm keeps the two-pass kernels on v_med3_i32 instead, and the MFMA kernels only use the instruction through
+    its builtin with the result cut to 16 bits.  If an update of the compiler brings the fused form back into the
+    two-pass kernels, or drops the instruction from the MFMA epilogues (their measured cost model), this raises --
+    the device-side known-answer test (mic_selftest, run by smoke()) is the check of the arithmetic itself."""
+    import re
+    import tempfile
+    flags = [f for f in _flags() if f not in ("-shared", "-fPIC")]
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "resample.s")
+        subprocess.check_call([hipcc(), f"--offload-arch={ARCH}"] + flags + ["-S", "--cuda-device-only", "-o", out,
+                                                                               os.path.join(CSRC, "kernels_resample.hip")],
+                              stderr=subprocess.DEVNULL)
+        with open(out, encoding="utf-8", errors="replace") as f:
+            text = f.read()
+    bodies = {}
+    for m in re.finditer(r"^(_ZN3mic\w+):.*?\n(.*?)s_endpgm", text, re.S | re.M):
+        bodies[m.group(1)] = m.group(2)
+    two_pass = [b for n, b in bodies.items() if "resample_h_kernel" in n or "resample_v_kernel" in n]
+    march = [b for n, b in bodies.items() if "resample_march_kernel" in n]
+    if len(two_pass) != 2 or len(march) != 1:
+        raise RuntimeError(f"check_isa: expected resample_h/v/march kernels in the assembly, found {sorted(bodies)}")
+    for b in two_pass:
+        if "v_ashr_pk_u8_i32" in b or "v_med3_i32" not in b:
+            raise RuntimeError("check_isa: the two-pass resample kernels no longer clamp with v_med3_i32 -- the compiler's own "
+                               "v_ashr_pk_u8_i32 fusion (which ORs a stale upper half, ROCm 7.2) is back: see clip8")
+    if march[0].count("v_ashr_pk_u8_i32") < 8 or march[0].count("v_ashr_pk_i8_i32") < 8:
+        raise RuntimeError("check_isa: the marching kernel's epilogues lost their v_ashr_pk_{u8,i8}_i32 (clip8x4)")
+    if verbose:
+        print("check_isa ok: two-pass kernels clamp with v_med3_i32, MFMA epilogues use v_ashr_pk_{u8,i8}_i32 via the builtin")
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

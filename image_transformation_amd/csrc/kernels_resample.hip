@@ -540,6 +540,83 @@ hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, size_t lds
     return hipGetLastError();
 }
 
+// ---- known-answer canary ------------------------------------------------------------------------------------------
+// hipcc 7.2 miscompiled "shift, clamp to 0..255, pack" (it ORs v_ashr_pk_u8_i32's 16-bit result as if the destination's
+// upper half were zero); clip8's empty asm and the explicit builtin + 16-bit truncation in clip8x4 work around it.
+// Nothing but the parity tests would notice a ROCm update that changes the lowering again, so the library carries a
+// tiny kernel that pushes known values through exactly these helpers -- every lane a different mix of negative,
+// in-range, saturating and boundary sums -- and mic_selftest compares with plain host arithmetic.
+__global__ void selftest_clip_kernel(uint32_t *__restrict__ out) {
+    const int l = threadIdx.x;
+    // four sums per lane around the interesting boundaries of clip8((bias + sum) >> 22) and sat8(v >> 6)
+    const int32_t base[8] = {INT32_MIN, -(1 << 22) - 1, -1, 0, (1 << 22) - 1, 255 << 22, (256 << 22) + 5, INT32_MAX};
+    int32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)  // (unsigned arithmetic: the sums wrap by definition)
+        v[j] = (int32_t)((uint32_t)base[(l + 3 * j) & 7] +
+                         (uint32_t)((int32_t)((uint32_t)l * 0x9E3779B1u >> (j + 3)) * ((l + j) & 1 ? 1 : -1) / 7));
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));  // values the compiler cannot fold
+    out[l * 4 + 0] = pack_clip(v[0], v[1], v[2], v[3]);
+    const v4i q = {v[0] >> 16, v[1] >> 16, v[2] >> 16, v[3] >> 16};  // the MFMA epilogue's range: sat8(q >> 6)
+    out[l * 4 + 1] = clip8x4(q);
+    out[l * 4 + 2] = clip8x4_signed(q);
+    out[l * 4 + 3] = premultiply((uint32_t)v[0]) ^ unpremultiply((uint32_t)v[1]);
+}
+
+static int32_t selftest_value(int l, int j) {
+    const int32_t base[8] = {INT32_MIN, -(1 << 22) - 1, -1, 0, (1 << 22) - 1, 255 << 22, (256 << 22) + 5, INT32_MAX};
+    return (int32_t)((uint32_t)base[(l + 3 * j) & 7] +
+                     (uint32_t)((int32_t)((uint32_t)l * 0x9E3779B1u >> (j + 3)) * ((l + j) & 1 ? 1 : -1) / 7));
+}
+
+// Runs the canary on `stream`, waits for it, and returns the number of mismatching words (0 = the helpers compute
+// what Pillow's arithmetic says); *first_bad (optional) names the first one.
+hipError_t run_selftest_clip(hipStream_t stream, int *mismatches, int *first_bad) {
+    uint32_t *dev = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&dev), 64 * 4 * sizeof(uint32_t));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(selftest_clip_kernel, dim3(1), dim3(64), 0, stream, dev);
+    uint32_t got[256];
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(got, dev, sizeof got, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return e;
+    auto c8 = [](int64_t v) { return (uint32_t)std::min<int64_t>(255, std::max<int64_t>(0, v)); };
+    auto c8s = [](int64_t v) { return (uint32_t)(std::min<int64_t>(127, std::max<int64_t>(-128, v)) & 255); };
+    auto d255 = [](uint32_t t) { return ((t >> 8) + t) >> 8; };
+    auto premul = [&](uint32_t p) {
+        const uint32_t a = p >> 24;
+        return d255((p & 255u) * a + 128u) | (d255(((p >> 8) & 255u) * a + 128u) << 8) | (d255(((p >> 16) & 255u) * a + 128u) << 16) | (a << 24);
+    };
+    auto unpremul = [](uint32_t p) {
+        const uint32_t a = p >> 24;
+        if (a == 0u || a == 255u) return p;
+        auto ch = [&](uint32_t c) { return std::min<uint32_t>(255u, 255u * c / a); };
+        return ch(p & 255u) | (ch((p >> 8) & 255u) << 8) | (ch((p >> 16) & 255u) << 16) | (a << 24);
+    };
+    int bad = 0, first = -1;
+    for (int l = 0; l < 64; ++l) {
+        int32_t v[4];
+        for (int j = 0; j < 4; ++j) v[j] = selftest_value(l, j);
+        uint32_t want[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 4; ++j) {
+            want[0] |= c8((int64_t)v[j] >> 22) << (8 * j);
+            want[1] |= c8(((int64_t)v[j] >> 16) >> 6) << (8 * j);
+            want[2] |= c8s(((int64_t)v[j] >> 16) >> 6) << (8 * j);
+        }
+        want[3] = premul((uint32_t)v[0]) ^ unpremul((uint32_t)v[1]);
+        for (int k = 0; k < 4; ++k)
+            if (got[l * 4 + k] != want[k]) {
+                if (first < 0) first = l * 4 + k;
+                ++bad;
+            }
+    }
+    *mismatches = bad;
+    if (first_bad) *first_bad = first;
+    return hipSuccess;
+}
+
 hipError_t launch_resample_h(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_rows,
                              hipStream_t stream) {
     if (n_jobs <= 0) return hipSuccess;

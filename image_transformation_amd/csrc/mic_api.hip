@@ -1631,6 +1631,18 @@ extern "C" int mic_draw_rect_outlines(mic_ctx *ctx, void *out_dev, int32_t width
     return MIC_OK;
 }
 
+// ------------------------------------------------------------------------------------ self test
+extern "C" int mic_selftest(mic_ctx *ctx, void *stream_v) {
+    CTX_ENTER(ctx);
+    int bad = 0, first = -1;
+    HIP_TRY(run_selftest_clip(static_cast<hipStream_t>(stream_v), &bad, &first));
+    if (bad)
+        return fail(MIC_ERR_HIP, "mic_selftest: %d of 256 known answers of the clip / pack helpers differ (first: word %d); the "
+                    "compiler lowers v_ashr_pk_u8_i32 or its neighbours differently from the build this library was "
+                    "validated with (kernels_resample.hip: clip8, clip8x4)", bad, first);
+    return MIC_OK;
+}
+
 // ------------------------------------------------------------------------------------ PIL-level drop-in helpers
 extern "C" int mic_host_rows_solid(const void *const *rows_host, int32_t width, int32_t y0, int32_t y1,
                                    const uint8_t rgba[4], int *is_solid) {

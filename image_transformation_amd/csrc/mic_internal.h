@@ -161,6 +161,8 @@ static_assert(sizeof(PlanarJob) == 32, "PlanarJob layout");
 hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream);
 hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_resample_tile(const RsTile *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes, hipStream_t stream);
+// Known-answer canary of the clip / pack / (un)premultiply helpers (kernels_resample.hip): 0 mismatches expected.
+hipError_t run_selftest_clip(hipStream_t stream, int *mismatches, int *first_bad);
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);
 // table_dev: scratch for max(W, H) <= 65535 colours (kGradientTableWords uint32)
 hipError_t launch_gradient(void *out, int W, int H, const uint8_t c1[3], const uint8_t c2[3], int vertical,

@@ -71,6 +71,11 @@ int mic_version(void);
 /* ---- context --------------------------------------------------------------------------- */
 int mic_create(int device, mic_ctx **out);
 int mic_destroy(mic_ctx *ctx);
+/* Known-answer canary: a tiny kernel pushes boundary values through the shift / saturate / pack helpers the resample
+ * kernels are built from (hipcc 7.2 miscompiled one such pattern -- v_ashr_pk_u8_i32 -- and the sources work around
+ * it) and the results are compared with host arithmetic.  MIC_ERR_HIP with the details if a ROCm update changes the
+ * lowering.  Synchronises `stream`.  Run by __graft_entry__.smoke() and the GPU tests.                          */
+int mic_selftest(mic_ctx *ctx, void *stream);
 /* Block until everything enqueued through this context on `stream` has finished. */
 int mic_sync(mic_ctx *ctx, void *stream);
 

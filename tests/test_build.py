@@ -80,3 +80,10 @@ def test_staleness_is_by_content_not_by_file_time(tmp_path):
     n = len(log.read_text().splitlines())
     subprocess.check_call([sys.executable, "-c", DRIVER, lib], env=dict(env, MIC_EXTRA_CFLAGS="-DX=1"), stdout=subprocess.DEVNULL)
     assert len(log.read_text().splitlines()) == n + 1
+
+
+def test_isa_canary_of_the_ashr_pk_workaround():
+    """build.check_isa (run by __graft_entry__.build()): the compiled resample kernels still have the shape the
+    v_ashr_pk_u8_i32 workaround relies on (no GPU needed: hipcc -S)."""
+    from image_transformation_amd import build
+    build.check_isa()

@@ -389,3 +389,10 @@ def test_pack_blob_into_pinned_memory_is_byte_identical():
     atlas = Atlas(objs)
     assert torch.equal(atlas.blob.cpu(), want)
     assert atlas[11].size == (5, 3) and len(atlas) == 4
+
+
+def test_selftest_canary(abi):
+    """mic_selftest: the known-answer kernel behind the v_ashr_pk_u8_i32 workaround (kernels_resample.hip clip8 / clip8x4)
+    agrees with host arithmetic on this compiler build."""
+    lib, ctx = abi[0], abi[1]
+    assert lib.mic_selftest(ctx, _stream()) == 0, lib.mic_last_error()
