@@ -42,8 +42,11 @@ class _PngWriter:
         self._pending: List[Any] = []
 
     def save(self, image: Image.Image, path) -> None:
-        big = image.size[0] * image.size[1] >= (1 << 21)
-        self._pending.append(self._pool.submit(mic_png.save, image, path, mic_png.DEFAULT_LEVEL, 0 if big else 1))
+        # a draft of the bundles' size (492 x 492) is ~1.3 ms of encoding on one core and the last one saved is the
+        # tail of the whole run: two stripes halve it; big images split themselves further (threads=0)
+        px = image.size[0] * image.size[1]
+        threads = 0 if px >= (1 << 21) else (2 if px >= (1 << 17) else 1)
+        self._pending.append(self._pool.submit(mic_png.save, image, path, mic_png.DEFAULT_LEVEL, threads))
 
     def close(self) -> None:
         try:
@@ -58,13 +61,19 @@ def read_original_size(bundle_dir: Path) -> Tuple[int, int]:
     return rgba_size(Path(bundle_dir) / "background.png")  # (decoded once per file version: the decode cache)
 
 
-def _iter_dirs(base: Path, idx: int) -> Dict[str, Path]:
+def _iter_dirs(base: Path, idx: int, made: Optional[Dict[int, Dict[str, Path]]] = None) -> Dict[str, Path]:
     """The reference's per-iteration artifact tree (macro_placement_test.py:1369-1379); the VLM
-    text/output folders are created too so that tools reading a run directory find the same shape."""
+    text/output folders are created too so that tools reading a run directory find the same shape.
+    `made`: the run's record of iterations whose folders exist already (each is created once)."""
+    if made is not None and idx in made:
+        return made[idx]
     out = base / f"iteration_{idx:02d}"
     dirs = {k: out / k for k in ("final_product", "vlm_input_text", "vlm_input_image", "vlm_output", "layout_json")}
+    out.mkdir(parents=True, exist_ok=True)
     for d in dirs.values():
-        d.mkdir(parents=True, exist_ok=True)
+        d.mkdir(exist_ok=True)
+    if made is not None:
+        made[idx] = dirs
     return dirs
 
 
@@ -110,8 +119,9 @@ def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, ori
     with open(results_json, "r", encoding="utf-8") as f:
         id_to_label = {int(it["object_id"]): str(it.get("label", it["object_id"])) for it in json.load(f)}
 
+    made: Dict[int, Dict[str, Path]] = {}
     if save:
-        d0 = _iter_dirs(base_out, 0)
+        d0 = _iter_dirs(base_out, 0, made)
         meta = {"ratio": ratio, "align": align, "margin": margin, "api": None,
                 "canvas_size": {"width": canvas_size[0], "height": canvas_size[1]},
                 "original_image": {"width": ow, "height": oh}, "refine_iters": max(0, len(flex_layouts) - 1)}
@@ -134,7 +144,7 @@ def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, ori
         drafts.append(draft)
         all_placements.append(final_json["placements"])
         if save:
-            d = _iter_dirs(base_out, i)
+            d = _iter_dirs(base_out, i, made)
             (d["layout_json"] / f"layout_macro_iter_{i:02d}.json").write_text(json.dumps(final_json, indent=2),
                                                                               encoding="utf-8")
             writer.save(draft, d["final_product"] / f"draft_macro_iter_{i:02d}.png")

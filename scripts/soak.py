@@ -8,18 +8,20 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np, torch
 import oracle
 from image_transformation_amd import _native, synthetic
-from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
+from PIL import Image
+from image_transformation_amd.background_resizing import median_colors_device
+from image_transformation_amd.compositor import Atlas, SolidCanvas, composite, composite_device, coerce_placements
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
 ctx = _native.context(); lib = _native.lib(); P = ctypes.c_void_p
 t_end = time.time() + budget
-n_comp = n_rs = 0
+n_comp = n_rs = n_pil = n_med = 0
 t_say = time.time() + 30
 while time.time() < t_end:
     if time.time() > t_say:  # progress line: long silent GPU runs are taken for hung
-        print(f"... {n_comp} composites, {n_rs} resizes so far", flush=True)
+        print(f"... {n_comp} composites, {n_pil} PIL composites, {n_med} medians, {n_rs} resizes so far", flush=True)
         t_say = time.time() + 30
     # ---- a random atlas + a few canvases
     objs = {i + 1: synthetic.make_cutout(rng, int(rng.integers(1, 260)), int(rng.integers(1, 200)),
@@ -62,6 +64,46 @@ while time.time() < t_end:
                                              sizes={k: v.shape for k, v in objs.items()}))
             sys.exit(1)
         n_comp += 1
+    # ---- round 3: the PIL-level drop-in (speculative solid background, layer records in the kernel arguments, small
+    # canvases written straight into pinned host memory, event-waited downloads) and the batched strided median
+    pil_objs = {k: Image.fromarray(v, "RGBA") for k, v in objs.items()}
+    for _ in range(3):
+        W, H = int(rng.integers(1, 900)), int(rng.integers(1, 700))
+        kind = int(rng.integers(0, 4))
+        col = tuple(int(v) for v in rng.integers(0, 256, 4)) if kind != 0 else (220, 238, 245, 255)
+        bg_np = np.empty((H, W, 4), np.uint8); bg_np[:] = col
+        if kind == 2:  # solid but for ONE byte somewhere: the speculative launch must be thrown away
+            bg_np[int(rng.integers(0, H)), int(rng.integers(0, W)), int(rng.integers(0, 4))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 3:
+            bg_np = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+        pl = []
+        for _k in range(int(rng.integers(1, 12))):
+            oid = int(rng.integers(1, len(objs) + 2))
+            sh, sw = objs.get(oid, objs[1]).shape[:2]
+            if rng.random() < 0.3:
+                sw, sh = max(1, int(sw * rng.uniform(0.3, 2.0))), max(1, int(sh * rng.uniform(0.3, 2.0)))
+            x1, y1 = int(rng.integers(-sw, W + 1)), int(rng.integers(-sh, H + 1))
+            pl.append({"object_id": oid, "box": [x1, y1, x1 + sw, y1 + sh]})
+        bg_im = Image.fromarray(bg_np, "RGBA")
+        got = np.array(composite(bg_im, pil_objs, pl))
+        if not np.array_equal(got, oracle.composite(bg_np, objs, pl)) or not np.array_equal(np.array(bg_im), bg_np):
+            print("PIL COMPOSITE MISMATCH", dict(seed=seed, W=W, H=H, kind=kind, pl=pl, sizes={k: v.shape for k, v in objs.items()}))
+            sys.exit(1)
+        n_pil += 1
+    mh, mw = int(rng.integers(1, 300)), int(rng.integers(1, 400))
+    m_np = rng.integers(0, 256, (mh, mw, 4), dtype=np.uint8)
+    m_np[:, :, 3] = np.where(rng.random((mh, mw)) < rng.random(), 0, m_np[:, :, 3])
+    m_dev = torch.from_numpy(m_np).cuda()
+    views, want_m = [], []
+    for _k in range(int(rng.integers(1, 22))):
+        y0, x0 = int(rng.integers(0, mh)), int(rng.integers(0, mw))
+        y1, x1 = int(rng.integers(y0 + 1, mh + 1)), int(rng.integers(x0 + 1, mw + 1))
+        views.append(m_dev[y0:y1, x0:x1])
+        want_m.append(oracle.median_rgb(np.ascontiguousarray(m_np[y0:y1, x0:x1])))
+    if median_colors_device(views) != want_m:
+        print("MEDIAN BATCH MISMATCH", dict(seed=seed, shape=(mh, mw), n=len(views)))
+        sys.exit(1)
+    n_med += len(views)
     # ---- a random resize
     sw, sh = int(rng.integers(1, 700)), int(rng.integers(1, 500))
     dw, dh = max(1, int(sw * rng.uniform(0.05, 3.0))), max(1, int(sh * rng.uniform(0.05, 3.0)))
@@ -83,4 +125,4 @@ while time.time() < t_end:
         print("PLAN RESIZE MISMATCH", dict(seed=seed, src=(sw, sh), dst=(dw, dh), filt=filt))
         sys.exit(1)
     n_rs += 1
-print(f"soak ok: {n_comp} composites, {n_rs} resizes, seed {seed}, {budget:.0f} s, MIC_RS_MARCH_MIN_UNITS={os.environ.get('MIC_RS_MARCH_MIN_UNITS')}")
+print(f"soak ok: {n_comp} composites, {n_pil} PIL drop-in composites, {n_med} batched medians, {n_rs} resizes, seed {seed}, {budget:.0f} s, MIC_RS_MARCH_MIN_UNITS={os.environ.get('MIC_RS_MARCH_MIN_UNITS')}")
