@@ -266,22 +266,25 @@ class Dist:
     """The N-rank protocol of the bench contract: barrier + synchronize on both sides of a timed region, MAX
     (and MIN) over ranks.  world == 1: everything is local."""
 
-    def __init__(self, world, rank, dev, rehearsal):
+    def __init__(self, world, rank, dev, rehearsal, active=None):
         self.world, self.rank, self.dev, self.rehearsal = world, rank, dev, rehearsal
+        # active: a process group exists and every collective below goes through it -- always at world > 1, and at
+        # world == 1 under MIC_BENCH_FORCE_DIST=1 (a one-rank RCCL communicator: the N > 1 code path on a one-GPU box)
+        self.active = world > 1 if active is None else active
         self.backend = None
-        if world > 1:
+        if self.active:
             import torch.distributed as dist
 
             self.backend = dist.get_backend()
 
     def barrier(self):
-        if self.world > 1:
+        if self.active:
             import torch.distributed as dist
 
             dist.barrier()
 
     def max_min(self, x: float):
-        if self.world == 1:
+        if not self.active:
             return x, x
         import torch
         import torch.distributed as dist
@@ -291,7 +294,7 @@ class Dist:
         return float(t[0].item()), -float(t[1].item())
 
     def sum(self, x: float) -> float:
-        if self.world == 1:
+        if not self.active:
             return x
         import torch
         import torch.distributed as dist
@@ -301,7 +304,7 @@ class Dist:
         return float(t[0].item())
 
     def gather(self, obj):
-        if self.world == 1:
+        if not self.active:
             return [obj]
         import torch.distributed as dist
 
@@ -349,12 +352,12 @@ def c4_strong_leg(D: Dist, args, steps, warmup):
     torch.cuda.synchronize()
     D.barrier()
     t0 = time.perf_counter()
-    atlas = broadcast_atlas(objs if D.rank == 0 or D.world == 1 else None, src=0)
+    atlas = broadcast_atlas(objs if D.rank == 0 or D.world == 1 else None, src=0, force=D.active)
     torch.cuda.synchronize()
     bcast_first_ms = (time.perf_counter() - t0) * 1e3
     D.barrier()
     t0 = time.perf_counter()
-    atlas = broadcast_atlas(objs if D.rank == 0 or D.world == 1 else None, src=0)
+    atlas = broadcast_atlas(objs if D.rank == 0 or D.world == 1 else None, src=0, force=D.active)
     torch.cuda.synchronize()
     bcast_warm_ms = (time.perf_counter() - t0) * 1e3
     ctx = atlas.ctx
@@ -429,17 +432,21 @@ def main():
                          "MIC_BENCH_REHEARSAL=1 shares cuda:0 between the ranks")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # MIC_BENCH_FORCE_DIST=1 (under torch.distributed.run with ONE rank): initialise the process group anyway, so that
+    # init_process_group("nccl", device_id=...), the NCCL barrier, GPU-tensor all_reduce / all_gather_object and the atlas
+    # broadcast run through RCCL on a one-GPU box -- the exact calls of an N > 1 run, with a one-rank communicator
+    dist_on = world > 1 or (os.environ.get("MIC_BENCH_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ)
+    if dist_on:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    D = Dist(world, rank, dev, rehearsal)
+    D = Dist(world, rank, dev, rehearsal, active=dist_on)
     devices = D.gather({"rank": rank, "device_index": dev_index, "name": torch.cuda.get_device_name(dev_index),
                         "pid": os.getpid()})
-    ranks_info = {"ranks": dist.get_world_size() if world > 1 else 1,
+    ranks_info = {"ranks": dist.get_world_size() if dist_on else 1,
                   "backend": (D.backend + (" (rehearsal: ranks share cuda:0)" if rehearsal else " (RCCL)" if D.backend == "nccl" else ""))
-                  if world > 1 else "none (single process)",
+                  if dist_on else "none (single process)",
                   "devices": devices}
 
     from image_transformation_amd import _native, flex, synthetic
@@ -464,7 +471,7 @@ def main():
         }
         if rank == 0:
             print(json.dumps(result), flush=True)
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -477,11 +484,11 @@ def main():
     # (or broadcast) costs once the process is warm is measured by doing it again.
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    atlas = broadcast_atlas(objs if rank == 0 or world == 1 else None, src=0)
+    atlas = broadcast_atlas(objs if rank == 0 or world == 1 else None, src=0, force=dist_on)
     torch.cuda.synchronize()
     atlas_first_ms = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter()
-    atlas = broadcast_atlas(objs if rank == 0 or world == 1 else None, src=0)
+    atlas = broadcast_atlas(objs if rank == 0 or world == 1 else None, src=0, force=dist_on)
     torch.cuda.synchronize()
     atlas_warm_ms = (time.perf_counter() - t0) * 1e3
     ctx = atlas.ctx
@@ -571,7 +578,7 @@ def main():
         "box_area_Mpixels_per_s": round(box_px * world * args.steps / elapsed / 1e6, 1),
         **ranks_info,
     }
-    if world > 1:
+    if dist_on:
         result["per_rank"] = {"timed_region_s_max": round(elapsed, 6), "timed_region_s_min": round(elapsed_min, 6),
                               "kernel_ms_max": round(kernel_ms_max, 4), "kernel_ms_min": round(kernel_ms_min, 4)}
 
@@ -597,7 +604,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
@@ -963,7 +970,9 @@ def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_
             c1_pil = {k: c1_objs[k] for k in c1_objs}
             c1 = {}
             for key, q in (("identity_scale", c1_pl), ("lanczos_x1.2", c1_pl2)):
-                t_mine, _ = _median_time(lambda: composite(c1_bg, c1_objs, q), 1.0, 300)
+                for _ in range(300):  # (steady state: clocks up, allocator and caches warm)
+                    composite(c1_bg, c1_objs, q)
+                t_mine, _ = _median_time(lambda: composite(c1_bg, c1_objs, q), 1.0, 5000)
                 t_pil, _ = _median_time(lambda: _pillow_composite(c1_bg, c1_pil, q), 1.0, 300)
                 c1[key] = {"this_package_us": round(t_mine * 1e6, 1), "pillow_us": round(t_pil * 1e6, 1)}
             # where the identity-scale call's time goes (stages timed on their own; profiles/r03_c1_breakdown.json has more)

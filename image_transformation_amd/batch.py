@@ -45,9 +45,10 @@ def broadcast_blob(blob, src: int = 0, device=None, group=None):
     return blob
 
 
-def broadcast_atlas(objects: Optional[Mapping[int, Any]], src: int = 0, group=None):
+def broadcast_atlas(objects: Optional[Mapping[int, Any]], src: int = 0, group=None, force: bool = False):
     """Rank `src` packs + uploads the cutouts, every rank ends up with a resident Atlas.
-    With a single process (no process group) this is just Atlas(objects)."""
+    With a single process (no process group, or a group of one unless force=True) this is just Atlas(objects);
+    force=True sends the blob through the collective even in a group of one (bench.py's one-rank RCCL rehearsal)."""
     import torch
     import torch.distributed as dist
 
@@ -55,7 +56,7 @@ def broadcast_atlas(objects: Optional[Mapping[int, Any]], src: int = 0, group=No
     from .compositor import Atlas, pack_blob
 
     ctx = _native.context()
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return Atlas(objects, ctx.device)
     rank = dist.get_rank(group)
     blob = None

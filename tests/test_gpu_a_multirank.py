@@ -117,3 +117,21 @@ def test_bench_c4_single_gpu_agrees_with_the_mixed_batch_leg():
     assert abs(c4["value"] / mixed - 1) < 0.05, (c4["value"], mixed)
     for key in ("c5_end_to_end", "contact_sheet", "run_layouts"):
         assert key in full, key
+
+
+def test_bench_one_rank_through_rccl():
+    """The calls an N > 1 run makes -- init_process_group("nccl", device_id=...), the NCCL barrier, GPU-tensor all_reduce,
+    all_gather_object, the atlas broadcast -- executed through RCCL itself with a ONE-rank communicator (the most a
+    one-GPU box allows: RCCL refuses two ranks on one device).  MIC_BENCH_FORCE_DIST=1 under torch.distributed.run."""
+    env = dict(os.environ, MIC_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MIC_BENCH_REHEARSAL", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "c4", "--steps", "6",
+           "--warmup", "2"]
+    res = subprocess.run(cmd, env=env, capture_output=True, timeout=420, cwd=ROOT)
+    text = res.stdout.decode("utf-8", "replace")
+    assert res.returncode == 0, text + res.stderr.decode("utf-8", "replace")[-3000:]
+    rec = json.loads([l for l in text.splitlines() if l.startswith("{")][0])
+    assert rec["ranks"] == 1 and rec["backend"].startswith("nccl") and "RCCL" in rec["backend"]
+    assert rec["config"]["canvases_per_step_total"] == 64 and rec["value"] > 0
+    assert rec["atlas"]["warm_ms_max"] > 0 and rec["per_rank"]["kernel_ms_max"] > 0
