@@ -34,20 +34,18 @@ namespace {
 
 // ---------------------------------------------------------------------------------------- checksums
 uint32_t g_crc[8][256];
-std::atomic<int> g_crc_ready{0};
+std::once_flag g_crc_once;
 
 void crc_init() {
-    if (g_crc_ready.load(std::memory_order_acquire)) return;
-    static uint32_t t[8][256];
-    for (uint32_t i = 0; i < 256; ++i) {
-        uint32_t c = i;
-        for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-        t[0][i] = c;
-    }
-    for (uint32_t i = 0; i < 256; ++i)
-        for (int s = 1; s < 8; ++s) t[s][i] = t[0][t[s - 1][i] & 255] ^ (t[s - 1][i] >> 8);
-    memcpy(g_crc, t, sizeof t);  // identical content from every thread that gets here
-    g_crc_ready.store(1, std::memory_order_release);
+    std::call_once(g_crc_once, [] {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            g_crc[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int s = 1; s < 8; ++s) g_crc[s][i] = g_crc[0][g_crc[s - 1][i] & 255] ^ (g_crc[s - 1][i] >> 8);
+    });
 }
 
 uint32_t crc32_update(uint32_t crc, const uint8_t *p, size_t n) {  // slicing-by-8; crc is the running (inverted) state
