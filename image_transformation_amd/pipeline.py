@@ -56,6 +56,24 @@ class _PngWriter:
             self._pool.shutdown(wait=True)
 
 
+class _Steps:
+    """The reference's per-step wall times (utils/timing.py StepTimer, macro_placement_test.py:1390-1711): the same
+    step names for the steps this harness runs (prepare, contact_sheet, compose_baseline, compose_iter_XX) and the
+    same `time_log.txt` lines ("name: 0.123s"); the full-precision seconds are returned in the result's "timings"."""
+
+    def __init__(self):
+        self.seconds: Dict[str, float] = {}
+
+    def add(self, name: str, t0: float) -> None:
+        import time
+        self.seconds[name] = self.seconds.get(name, 0.0) + (time.perf_counter() - t0)
+
+    def write(self, path) -> None:
+        with open(path, "w", encoding="utf-8") as f:
+            for k, v in self.seconds.items():
+                f.write(f"{k}: {v:.3f}s\n")
+
+
 def read_original_size(bundle_dir: Path) -> Tuple[int, int]:
     """macro_placement_test.py:154-157."""
     return rgba_size(Path(bundle_dir) / "background.png")  # (decoded once per file version: the decode cache)
@@ -88,11 +106,15 @@ def run_layouts(bundle_dir: str, ratio: str, flex_layouts: Sequence[Dict[str, An
     With save=True the artifacts go to <output_root>/<bundle name>/iteration_XX/... with the
     reference's file names; a previous run directory for the same bundle is removed first (:1381-1387).
     """
+    import time
+    steps = _Steps()
+    t0 = time.perf_counter()
     bundle = Path(bundle_dir)
     results_json = bundle / "results.json"
     bg_path = bundle / "background.png"
     ow, oh = read_original_size(bundle)
     canvas_size = compute_canvas_size((ow, oh), ratio, quiet=quiet)
+    steps.add("prepare", t0)  # (:1396)
 
     base_out: Optional[Path] = None
     if save:
@@ -102,17 +124,24 @@ def run_layouts(bundle_dir: str, ratio: str, flex_layouts: Sequence[Dict[str, An
         base_out.mkdir(parents=True, exist_ok=True)
     writer = _PngWriter() if save else None
     try:
-        return _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, (ow, oh), align, margin, save)
+        res = _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, (ow, oh), align, margin, save, steps)
+        res["timings"] = dict(steps.seconds)
+        if save:
+            steps.write(base_out / "time_log.txt")  # (:1711)
+        return res
     finally:
         if writer is not None:
             writer.close()
 
 
-def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, original_size, align, margin, save):
+def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, original_size, align, margin, save, steps):
+    import time
     results_json = bundle / "results.json"
     bg_path = bundle / "background.png"
     ow, oh = original_size
+    t0 = time.perf_counter()
     sheet = build_labeled_contact_sheet(str(bundle / "objects"), str(results_json), view=True)
+    steps.add("contact_sheet", t0)  # (:1413)
     canvas: SolidCanvas = solid_canvas(str(bg_path), canvas_size)
     objects = load_object_images(str(results_json), shared=True)  # resident atlas on first use
     atlas = objects.atlas()
@@ -133,6 +162,7 @@ def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, ori
     drafts: List[Image.Image] = []
     all_placements: List[List[Dict]] = []
     for i, flex_raw in enumerate(flex_layouts):
+        t0 = time.perf_counter()
         placements = layout_to_placements(flex_raw, objects, canvas_size)
         final_json = {
             "canvas": {"width": canvas_size[0], "height": canvas_size[1], "margin": margin, "align": align},
@@ -152,5 +182,6 @@ def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, ori
                         d["final_product"] / f"overlay_debug_iter_{i:02d}.png")  # :1514, :1700
             (d["layout_json"] / f"provenance_iter_{i:02d}.json").write_text(
                 json.dumps({"method": "flex", "fallback": False, "iteration": i}, indent=2), encoding="utf-8")
+        steps.add("compose_baseline" if i == 0 else f"compose_iter_{i:02d}", t0)  # (:1492, :1678)
     return {"canvas_size": canvas_size, "background_rgba": canvas.rgba, "contact_sheet": sheet, "drafts": drafts,
             "placements": all_placements, "output_dir": str(base_out) if base_out else None}

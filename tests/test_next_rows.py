@@ -177,6 +177,11 @@ def test_run_layouts_harness_matches_reference_goldens(golden_dir, tmp_path):
             lj = json.load(f)
         assert lj["canvas"] == {"width": 492, "height": 492, "margin": 0.05, "align": "center"}
         assert [p["name"] for p in lj["placements"]] and all("box" in p and "cell" in p for p in lj["placements"])
+    # the reference's time_log.txt (utils/timing.py): its step names and line format for the steps the harness runs
+    with open(os.path.join(out, "time_log.txt"), encoding="utf-8") as f:
+        log = [l.strip() for l in f]
+    assert [l.split(":")[0] for l in log] == ["prepare", "contact_sheet", "compose_baseline", "compose_iter_01", "compose_iter_02"]
+    assert all(l.endswith("s") and float(l.split(": ")[1][:-1]) >= 0 for l in log) and set(res["timings"]) == {l.split(":")[0] for l in log}
     from PIL import Image
     saved = np.array(Image.open(os.path.join(out, "iteration_00", "final_product", "draft_macro_iter_00.png")).convert("RGBA"))
     assert np.array_equal(saved, arrays["squarespace_1x1"])
