@@ -165,6 +165,30 @@ def copy_to_pipelined(img: Image.Image, dst_addr: int, on_piece) -> bool:
     return True
 
 
+def same_pixels(a: Image.Image, b: Image.Image) -> bool:
+    """Do two RGBA images hold the same size and bytes?  memcmp over Pillow's own rows (no tobytes() copies); False
+    also when either image's memory cannot be located."""
+    if a.size != b.size or a.mode != "RGBA" or b.mode != "RGBA":
+        return False
+    ta, tb = row_table(a), row_table(b)
+    if ta is None or tb is None:
+        return False
+    W, H = a.size
+    ra = (ctypes.c_uint64 * H).from_address(ta[0])
+    rb = (ctypes.c_uint64 * H).from_address(tb[0])
+    line = 4 * W
+    # rows of one image are contiguous in long runs: compare run by run
+    y = 0
+    while y < H:
+        n = 1
+        while y + n < H and ra[y + n] == ra[y] + n * line and rb[y + n] == rb[y] + n * line:
+            n += 1
+        if _libc.memcmp(ra[y], rb[y], n * line) != 0:
+            return False
+        y += n
+    return True
+
+
 def copy_from(img: Image.Image, src_addr: int) -> bool:
     """memmove W*H*4 tightly packed bytes at src_addr INTO the image's own rows (an Image.new the caller owns).
     False: the image's memory could not be located (the caller builds the image another way)."""

@@ -77,6 +77,17 @@ class _DecodeCache:
         return im.copy()
 
     @classmethod
+    def pristine(cls, path) -> Optional[Image.Image]:
+        """The cached decode itself (never handed to callers): what a private copy is compared with."""
+        p = os.fspath(path)
+        try:
+            st = os.stat(p)
+        except OSError:
+            return None
+        with cls._lock:
+            return cls._items.get((os.path.abspath(p), st.st_mtime_ns, st.st_size))
+
+    @classmethod
     def size(cls, path) -> Tuple[int, int]:
         p = os.fspath(path)
         st = os.stat(p)
@@ -381,13 +392,15 @@ class ObjectImages(dict):
     is dropped whenever the dict is modified."""
 
     _atlas: Optional[Atlas] = None
-    # set by load_object_images(shared=True): identifies the files the dict's READ-ONLY views were decoded from, with
-    # the Pillow core object of every view.  Only such dicts share the process-wide device atlas of their files: a
-    # view that Pillow has copied-on-write (putalpha, paste, ImageDraw ... replace im.im and clear im.readonly) no
-    # longer shows the file's pixels and the dict then uploads an atlas of its own.  Private copies (the default
-    # load_object_images(), mutable like the reference's) always get an atlas built from the dict's own images.
+    # set by load_object_images: identifies the files the dict was decoded from.  A dict shares the process-wide device
+    # atlas of its files only while its images provably show the files' pixels: READ-ONLY views (shared=True) are
+    # checked on every use (Pillow's copy-on-write -- putalpha, paste, ImageDraw ... -- replaces im.im and clears
+    # im.readonly: _views_intact); private copies (the default, mutable like the reference's) are compared byte for byte
+    # with the decode cache once, when the dict first needs an atlas (_copies_pristine).  Anything else uploads an
+    # atlas built from the dict's own images.
     _source_key = None
     _cores = None
+    _paths = None  # private copies (the default load): {id: file path}, to compare with the decode cache on first use
 
     def _views_intact(self) -> bool:
         cores = self._cores
@@ -398,16 +411,34 @@ class ObjectImages(dict):
                 return False
         return True
 
+    def _copies_pristine(self) -> bool:
+        """Private copies (the default load_object_images()): do they still hold exactly the files' pixels?  One memcmp
+        per cutout against the decode cache, done ONCE, when the dict first needs an atlas: the reference reloads the
+        bundle every iteration (macro_placement_test.py:1493, 1679) and every such dict can then share the ONE device
+        atlas of the files instead of uploading its own; a copy that was edited in place before first use fails the
+        comparison and the dict uploads what it holds."""
+        paths = self._paths
+        if not paths or len(paths) != len(self):
+            return False
+        for k, im in self.items():
+            ref = _DecodeCache.pristine(paths.get(k, "")) if k in paths else None
+            if ref is None or not _pilmem.same_pixels(im, ref):
+                return False
+        return True
+
     def atlas(self, device: Optional[int] = None) -> Atlas:
-        if self._atlas is not None and self._source_key is not None and not self._views_intact():
+        if self._atlas is not None and self._cores is not None and not self._views_intact():
             self._touch()  # a view was written to since the atlas was taken from the shared cache
         if self._atlas is None or (device is not None and self._atlas.ctx.device != device):
-            if self._source_key is not None and self._views_intact():
+            shared_ok = self._source_key is not None and (self._views_intact() if self._cores is not None
+                                                          else self._copies_pristine())
+            if shared_ok:
                 dev = _native.context(device).device
                 self._atlas = _AtlasCache.get(self._source_key, dev, lambda: Atlas(self, device))
             else:
                 self._source_key = None
                 self._atlas = Atlas(self, device)
+            self._paths = None  # (compared once; later in-place edits are announced with invalidate())
         return self._atlas
 
     def invalidate(self) -> None:
@@ -423,6 +454,7 @@ class ObjectImages(dict):
         self._native_table = None
         self._source_key = None  # no longer what the files hold
         self._cores = None
+        self._paths = None
 
     def __setitem__(self, k, v):
         self._touch()
@@ -483,11 +515,13 @@ def load_object_images(results_json_path: str, shared: bool = False) -> Dict[int
         out[int(it["object_id"])] = open_rgba(path, shared)
         st = os.stat(path)
         keys.append((int(it["object_id"]), os.path.abspath(path), st.st_mtime_ns, st.st_size))
-    if shared:  # (after the inserts above, which reset it)
-        out._source_key = tuple(keys)
+    out._source_key = tuple(keys)  # (after the inserts above, which reset it)
+    if shared:
         out._cores = {k: getattr(im, "im", None) for k, im in out.items()}
-        if not out._views_intact():  # a Pillow without copy-on-write views: private copies, private atlas
-            out._source_key = out._cores = None
+        if not out._views_intact():  # a Pillow without copy-on-write views: treat them as private copies
+            out._cores = None
+    if out._cores is None:
+        out._paths = {k[0]: k[1] for k in keys}
     return out
 
 

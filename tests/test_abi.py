@@ -241,21 +241,30 @@ def test_atlas_cache_is_only_for_intact_shared_views(tmp_path, monkeypatch):
     compositor._AtlasCache._items.clear()
 
     private = compositor.load_object_images(str(rj))
-    assert private._source_key is None
     private[1].putalpha(7)                                  # in-place edit BEFORE first use
     a = private.atlas()
     assert a.pixels[1] == private[1].tobytes() and private[1].getpixel((0, 0))[3] == 7
-    assert not compositor._AtlasCache._items                # private copies never touch the shared cache
+    assert not compositor._AtlasCache._items and private._source_key is None  # an edited copy never touches the shared cache
+    # untouched private copies (the reference reloads the bundle every iteration): compared with the decode cache once,
+    # then every such dict shares the files' ONE atlas
+    p1, p2 = compositor.load_object_images(str(rj)), compositor.load_object_images(str(rj))
+    assert p1[1] is not p2[1] and p1.atlas() is p2.atlas() and len(compositor._AtlasCache._items) == 1
+    n_before = len(built)
+    p3 = compositor.load_object_images(str(rj))
+    p3[2].paste((1, 2, 3, 4), (0, 0, 2, 2))                 # edited before first use: its own atlas
+    assert p3.atlas() is not p1.atlas() and len(built) == n_before + 1 and p3.atlas().pixels[2] == p3[2].tobytes()
+    compositor._AtlasCache._items.clear()
+    built.clear()
 
     s1 = compositor.load_object_images(str(rj), shared=True)
     s2 = compositor.load_object_images(str(rj), shared=True)
-    assert s1._source_key is not None and s1.atlas() is s2.atlas() and len(built) == 2
+    assert s1._source_key is not None and s1.atlas() is s2.atlas() and len(built) == 1
     s2[2].putalpha(9)                                       # Pillow copies the view before it writes
     assert s2[2].readonly == 0
     a2 = s2.atlas()
     assert a2 is not s1.atlas() and a2.pixels[2] == s2[2].tobytes() and s2._source_key is None
-    assert s1.atlas() is built[1]                           # the untouched dict still shares the files' atlas
+    assert s1.atlas() is built[0]                           # the untouched dict still shares the files' atlas
     s3 = compositor.load_object_images(str(rj), shared=True)
-    assert s3.atlas() is built[1]
+    assert s3.atlas() is built[0]
     s3.invalidate()
-    assert s3.atlas() is not built[1]
+    assert s3.atlas() is not built[0]

@@ -107,3 +107,23 @@ def test_pipelined_copy_reports_pieces_in_order_and_covers_everything():
     assert [o for o, _ in seen] == sorted(o for o, _ in seen) and seen[0][0] == 0
     assert sum(n for _, n in seen) == a.size and all(seen[i][0] + seen[i][1] == seen[i + 1][0] for i in range(len(seen) - 1))
     assert np.array_equal(dst.reshape(a.shape), a)
+
+
+def test_same_pixels_is_an_exact_byte_comparison():
+    rng = np.random.default_rng(12)
+    for size in ((7, 5), (492, 492), (2300, 2100)):
+        a = rng.integers(0, 256, (size[1], size[0], 4), dtype=np.uint8)
+        im1 = Image.fromarray(a, "RGBA")
+        im2 = Image.new("RGBA", size)
+        im2.paste(im1)  # other memory layout (Pillow's block allocator above 16 MB)
+        assert _pilmem.same_pixels(im1, im2) and _pilmem.same_pixels(im2, im1.copy())
+        for (x, y) in ((0, 0), (size[0] - 1, size[1] - 1), (size[0] // 2, size[1] // 2)):
+            px = list(im2.getpixel((x, y)))
+            px[3] ^= 1
+            im2.putpixel((x, y), tuple(px))
+            assert not _pilmem.same_pixels(im1, im2)
+            px[3] ^= 1
+            im2.putpixel((x, y), tuple(px))
+        assert _pilmem.same_pixels(im1, im2)
+    assert not _pilmem.same_pixels(Image.new("RGBA", (4, 4)), Image.new("RGBA", (4, 5)))
+    assert not _pilmem.same_pixels(Image.new("RGBA", (4, 4)), Image.new("RGB", (4, 4)))
