@@ -316,6 +316,18 @@ const FixedCodes kFixed;
 
 void emit_tokens(BitWriter &bw, const uint32_t *tok, size_t n, const uint8_t *ll_len, const uint16_t *ll_code,
                  const uint8_t *d_len, const uint16_t *d_code) {
+    // per length symbol / distance symbol: the code with room for the extra bits above it, so that a match is two
+    // puts (length + its extra, distance + its extra: at most 15 + 5 and 15 + 13 bits) instead of four
+    uint32_t lcode[29], dcode[30];
+    uint8_t lbits[29], dbits[30];
+    for (int s = 0; s < 29; ++s) {
+        lcode[s] = ll_code[257 + s];
+        lbits[s] = ll_len[257 + s];
+    }
+    for (int s = 0; s < 30; ++s) {
+        dcode[s] = d_code[s];
+        dbits[s] = d_len[s];
+    }
     for (size_t i = 0; i < n; ++i) {
         const uint32_t t = tok[i];
         if (!(t & kMatchFlag)) {
@@ -324,11 +336,9 @@ void emit_tokens(BitWriter &bw, const uint32_t *tok, size_t n, const uint8_t *ll
         }
         const int len = (int)((t >> 16) & 0x7fff) + 3, dist = (int)(t & 0xffff) + 1;
         const int ls = kT.len_sym[len];
-        bw.put(ll_code[257 + ls], ll_len[257 + ls]);
-        if (kLenExtra[ls]) bw.put((uint32_t)(len - kLenBase[ls]), kLenExtra[ls]);
+        bw.put(lcode[ls] | ((uint32_t)(len - kLenBase[ls]) << lbits[ls]), lbits[ls] + kLenExtra[ls]);
         const int ds = dist_symbol(dist);
-        bw.put(d_code[ds], d_len[ds]);
-        if (kDistExtra[ds]) bw.put((uint32_t)(dist - kDistBase[ds]), kDistExtra[ds]);
+        bw.put(dcode[ds] | ((uint32_t)(dist - kDistBase[ds]) << dbits[ds]), dbits[ds] + kDistExtra[ds]);
     }
     bw.put(ll_code[256], ll_len[256]);
 }
