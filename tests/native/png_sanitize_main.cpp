@@ -1,0 +1,61 @@
+// libmic's PNG encoder (csrc/png_encode.cpp) under AddressSanitizer / UBSan: every image kind and size class the
+// bound computation (deflate_bound), the unchecked bit writer and the stripe logic have to survive -- incompressible
+// noise (stored fallback), flat images (run fast path), periodic patterns (long-distance matches), one-pixel and
+// one-row / one-column shapes, widths around the SSE chunking, every level / thread count.  Prints the FNV-1a of
+// all encoded bytes so that a second run can be compared.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "png_encode.h"
+
+static uint64_t g_hash = 1469598103934665603ull;
+static void mix(const uint8_t *p, size_t n) {
+    for (size_t i = 0; i < n; ++i) g_hash = (g_hash ^ p[i]) * 1099511628211ull;
+}
+
+int main() {
+    uint32_t s = 12345;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
+    const int sizes[][2] = {{1, 1}, {1, 777}, {999, 1}, {3, 3}, {4, 5}, {5, 4}, {15, 9}, {16, 9}, {17, 9}, {63, 7}, {64, 7}, {65, 7},
+                            {131, 97}, {492, 492}, {1025, 300}, {37, 2500}, {4099, 33}, {16385, 3}};
+    int n_ok = 0;
+    for (const auto &wh : sizes) {
+        const int w = wh[0], h = wh[1];
+        for (int kind = 0; kind < 6; ++kind) {
+            std::vector<uint8_t> img((size_t)w * h * 4);
+            for (size_t i = 0; i < img.size(); ++i) {
+                const size_t px = i / 4, x = px % w, y = px / w;
+                switch (kind) {
+                    case 0: img[i] = (uint8_t)rnd(); break;                                   // noise
+                    case 1: img[i] = (uint8_t)(0x11 * (i % 4 + 1)); break;                    // flat
+                    case 2: img[i] = (uint8_t)((x * 3 + y * 5 + i % 4) & 255); break;         // ramps
+                    case 3: img[i] = (uint8_t)(((x & 7) * 31 + (y & 7) * 17 + i % 4) & 255); break;  // 8 x 8 tiles
+                    case 4: img[i] = (y % 3 == 0) ? 255 : 0; break;                           // stripes
+                    default: img[i] = (x > (size_t)w / 2) ? (uint8_t)rnd() : 7; break;        // half flat, half noise
+                }
+            }
+            std::vector<const uint8_t *> rows((size_t)h);
+            for (int y = 0; y < h; ++y) rows[(size_t)y] = img.data() + (size_t)y * w * 4;
+            for (int level = 0; level <= 1; ++level)
+                for (int threads : {1, 2, 3, 0}) {
+                    mic::PngPieces out;
+                    std::string err;
+                    if (mic::png_encode_rows(rows.data(), w, h, level, threads, &out, &err) != 0) {
+                        printf("encode failed: %s\n", err.c_str());
+                        return 1;
+                    }
+                    if (out.total() > mic::png_bound(w, h)) {
+                        printf("bound exceeded %dx%d kind %d\n", w, h, kind);
+                        return 1;
+                    }
+                    for (const auto &p : out.pieces) mix(p.data, p.size);
+                    ++n_ok;
+                }
+        }
+    }
+    printf("ok=%d hash=%016llx\n", n_ok, (unsigned long long)g_hash);
+    return 0;
+}

@@ -102,3 +102,25 @@ def test_flex_parser_and_tables_under_asan_ubsan(binary, golden_dir):
     assert out.startswith("ok=") and b"ERROR" not in r.stderr and b"runtime error" not in r.stderr, r.stderr[-3000:]
     ok = int(out.split()[0].split("=")[1])
     assert ok >= 240  # the fixture trees themselves are still placed
+
+
+def test_png_encoder_under_asan_ubsan(tmp_path):
+    """csrc/png_encode.cpp (the artifacts' encoder: an unchecked bit writer sized by deflate_bound, pooled scratch, worker
+    threads) compiled with -fsanitize=address,undefined and driven with noise / flat / periodic / striped images of the
+    size classes around its chunkings, every level and thread count; two runs produce the same bytes."""
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    out = str(tmp_path / "png_sanitize")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-I", CSRC, os.path.join(ROOT, "tests", "native", "png_sanitize_main.cpp"),
+           os.path.join(CSRC, "png_encode.cpp"), "-lpthread", "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "asan" in (r.stderr or "").lower() and "cannot find" in r.stderr.lower():
+        pytest.skip("libasan not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    runs = [subprocess.run([out], capture_output=True, env=env, timeout=900) for _ in range(2)]
+    for r in runs:
+        assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+        assert r.stdout.startswith(b"ok=") and b"ERROR" not in r.stderr and b"runtime error" not in r.stderr, r.stderr[-3000:]
+    assert runs[0].stdout == runs[1].stdout  # deterministic bytes, whatever the thread scheduling
