@@ -18,6 +18,7 @@ import numpy as np
 from PIL import Image
 
 from . import _native
+from . import png as mic_png
 from .compositor import SolidCanvas, _to_pil, composite_device, Atlas, coerce_placements
 
 _P = ctypes.c_void_p
@@ -70,7 +71,7 @@ def overlay_debug(placements: Sequence[Dict], canvas_size: Tuple[int, int]) -> I
 
 def save_overlay_debug(placements: Sequence[Dict], canvas_size: Tuple[int, int], path) -> None:
     """Drop-in for _save_overlay_debug(placements, canvas_size, path)."""
-    overlay_debug(placements, canvas_size).save(path)
+    mic_png.save_like_pil(overlay_debug(placements, canvas_size), path)  # (*.png: libmic's writer)
 
 
 def candidates_grid_device(images: Sequence[Image.Image]):
@@ -94,4 +95,4 @@ def compose_candidates_grid(image_paths: Sequence, out_path) -> None:
     imgs: List[Image.Image] = [Image.open(p).convert("RGBA") for p in image_paths if Path(p).exists()]
     if not imgs:
         return
-    _to_pil(candidates_grid_device(imgs)).save(out_path)
+    mic_png.save_like_pil(_to_pil(candidates_grid_device(imgs)), out_path)

@@ -92,3 +92,13 @@ def encode(image, level: int = DEFAULT_LEVEL, threads: int = 0) -> bytes:
         _native.check(lib.mic_png_encode(_P(ptr), W, H, stride, int(level), int(threads), _P(buf.ctypes.data), cap, ctypes.byref(n)))
     del keep
     return buf[:n.value].tobytes()
+
+
+def save_like_pil(image: Image.Image, path, **pil_kwargs) -> None:
+    """image.save(path) as the reference's helpers call it (_save_overlay_debug, _compose_candidates_grid): PIL picks
+    the format from the file name, so only *.png goes through libmic's writer; any other name (or explicit PIL
+    options) is PIL's business."""
+    if not pil_kwargs and isinstance(image, Image.Image) and image.mode == "RGBA" and os.fspath(path).lower().endswith(".png"):
+        save(image, path)
+    else:
+        image.save(path, **pil_kwargs)

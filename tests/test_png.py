@@ -126,3 +126,16 @@ def test_png_errors():
         mic_png.save(np.zeros((4, 4, 4), np.uint8), "/nonexistent-dir/x.png")
     rgb = Image.new("RGB", (5, 4), (1, 2, 3))  # other modes are converted like .convert("RGBA")
     assert np.array_equal(np.array(Image.open(io.BytesIO(mic_png.encode(rgb)))), np.array(rgb.convert("RGBA")))
+
+
+def test_save_like_pil_only_takes_png_names(tmp_path):
+    """The reference's helpers call image.save(path) and PIL picks the format from the name: only *.png goes through
+    libmic's writer."""
+    im = Image.fromarray(_images()["canvas_like"], "RGBA")
+    mic_png.save_like_pil(im, tmp_path / "a.PNG")
+    assert (tmp_path / "a.PNG").read_bytes() == mic_png.encode(im)
+    mic_png.save_like_pil(im, tmp_path / "a.bmp")
+    assert Image.open(tmp_path / "a.bmp").format == "BMP"
+    mic_png.save_like_pil(im, tmp_path / "b.png", compress_level=9)  # explicit PIL options: PIL's encoder
+    assert (tmp_path / "b.png").read_bytes() != mic_png.encode(im)
+    assert np.array_equal(np.array(Image.open(tmp_path / "b.png")), np.array(im))
