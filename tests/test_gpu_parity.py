@@ -677,3 +677,32 @@ def test_in_place_edit_of_a_loaded_cutout_is_seen(gpu, tmp_path):
     shared = load_object_images(rj, shared=True)
     shared[2].putalpha(90)  # copy-on-write view: detected, private atlas
     assert np.array_equal(np.array(composite(bg, shared, pl)), want)
+
+
+def test_layer_records_in_kernel_arguments_boundary(gpu):
+    """A single-canvas launch carries its layer records in the kernel arguments up to 64 of them (kPackLayers) and reads
+    the device table beyond: 1, 63, 64, 65 and 130 layers, one-shot (mic_composite_batch) and persistent (mic_plan_*)
+    launches, identity and resampled layers, all equal to the oracle."""
+    from image_transformation_amd.compositor import Atlas, CompositeBatch, SolidCanvas, composite_device, coerce_placements
+    syn = cases.synthetic
+    rng = np.random.default_rng(64)
+    objs = syn.make_cutouts(9, (20, 70), (15, 60), seed=640, alpha_mode="soft")
+    atlas = Atlas(objs)
+    W, H = 801, 333
+    for n in (1, 63, 64, 65, 130):
+        for resample in (False, True):
+            pl = []
+            for k in range(n):
+                oid = int(rng.integers(1, 10))
+                sh, sw = objs[oid].shape[:2]
+                if resample and k % 5 == 0:
+                    sw, sh = max(1, int(sw * 1.3)), max(1, int(sh * 0.8))
+                x1, y1 = int(rng.integers(-10, W)), int(rng.integers(-10, H))
+                pl.append({"object_id": oid, "box": [x1, y1, x1 + sw, y1 + sh]})
+            rows = coerce_placements(atlas, pl)
+            want = oracle.composite(_solid(W, H), objs, pl)
+            got = composite_device(atlas, [SolidCanvas((W, H), syn.SOLID_BG)], [rows])[0].cpu().numpy()
+            assert np.array_equal(got, want), (n, resample, "one-shot")
+            plan = CompositeBatch(atlas, [SolidCanvas((W, H), syn.SOLID_BG)], [rows])
+            for _ in range(2):
+                assert np.array_equal(plan.run()[0].cpu().numpy(), want), (n, resample, "plan")
