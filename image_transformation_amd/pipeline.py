@@ -15,6 +15,7 @@ and only the finished draft is copied back for the PNG encoder.  This is SURVEY.
 from __future__ import annotations
 
 import json
+import os
 import shutil
 from pathlib import Path
 from typing import Any, Dict, List, Optional, Sequence, Tuple
@@ -82,6 +83,28 @@ class _Steps:
                 f.write(f"{k}: {v:.3f}s\n")
 
 
+def _remove_tree(path: Path) -> None:
+    """shutil.rmtree(path, ignore_errors=True) for the artifact tree this module writes: two levels of folders with a
+    few files each.  One scandir per folder, unlink / rmdir directly (rmtree's fd-based walk costs ~3x the syscalls);
+    anything unexpected falls back to rmtree."""
+    try:
+        stack = [os.fspath(path)]
+        dirs = []
+        while stack:
+            d = stack.pop()
+            dirs.append(d)
+            with os.scandir(d) as it:
+                for e in it:
+                    if e.is_dir(follow_symlinks=False):
+                        stack.append(e.path)
+                    else:
+                        os.unlink(e.path)
+        for d in reversed(dirs):
+            os.rmdir(d)
+    except OSError:
+        shutil.rmtree(path, ignore_errors=True)
+
+
 def read_original_size(bundle_dir: Path) -> Tuple[int, int]:
     """macro_placement_test.py:154-157."""
     return rgba_size(Path(bundle_dir) / "background.png")  # (decoded once per file version: the decode cache)
@@ -128,7 +151,7 @@ def run_layouts(bundle_dir: str, ratio: str, flex_layouts: Sequence[Dict[str, An
     if save:
         base_out = Path(output_root or "output_macro_placement") / bundle.name
         if base_out.exists():
-            shutil.rmtree(base_out, ignore_errors=True)
+            _remove_tree(base_out)  # a previous run for the same bundle goes first (:1381-1387)
         base_out.mkdir(parents=True, exist_ok=True)
     writer = _PngWriter() if save else None
     try:
