@@ -14,7 +14,7 @@ from typing import Dict, Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MIC_LIB") or os.path.join(_HERE, "libmic.so")  # MIC_LIB: an alternative build (tuning runs)
 
-ABI_VERSION = (1, 7)  # mic_version(): include/mic.h as this file binds it
+ABI_VERSION = (1, 8)  # mic_version(): include/mic.h as this file binds it
 LANCZOS = 0
 BILINEAR = 1
 ERR_FORMAT = -5
@@ -119,6 +119,9 @@ SYMBOLS = {
     "mic_png_write": (ctypes.c_int, [ctypes.c_char_p, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, ctypes.c_int,
                                      ctypes.c_int]),
     "mic_png_write_rows": (ctypes.c_int, [ctypes.c_char_p, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_int]),
+    "mic_png_write_async": (ctypes.c_int, [ctypes.c_char_p, _P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_int,
+                                           ctypes.POINTER(ctypes.c_int64)]),
+    "mic_png_wait": (ctypes.c_int, [ctypes.c_int64]),
     "mic_last_stats": (ctypes.c_int, [_P, ctypes.POINTER(Stats)]),
     "mic_profile_begin": (ctypes.c_int, [_P, ctypes.c_int]),
     "mic_profile_begin_sampled": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int]),

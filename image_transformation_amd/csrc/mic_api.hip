@@ -52,7 +52,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *mic_last_error(void) { return g_err; }
-extern "C" int mic_version(void) { return (1 << 16) | 7; }  // 1.7: + mic_median_rgb_batch, mic_host_rows_solid, mic_download(_wait); 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
+extern "C" int mic_version(void) { return (1 << 16) | 8; }  // 1.8: + mic_png_write_async / mic_png_wait; 1.7: + mic_median_rgb_batch, mic_host_rows_solid, mic_download(_wait); 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
 
 // ------------------------------------------------------------------------------------ blob layout
 namespace {
@@ -1740,30 +1740,29 @@ static int png_to_memory(const mic::PngPieces &pieces, void *out, size_t capacit
 }
 
 static int png_to_file(const mic::PngPieces &pieces, const char *path) {
-    if (!path) return fail(MIC_ERR_INVALID, "mic_png_write: null path");
-    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
-    if (fd < 0) return fail(MIC_ERR_INVALID, "mic_png_write: cannot open %s: %s", path, strerror(errno));
-    std::vector<iovec> iov;
-    for (const auto &p : pieces.pieces)
-        if (p.size) iov.push_back(iovec{const_cast<uint8_t *>(p.data), p.size});
-    size_t i = 0;
-    int rc = MIC_OK;
-    while (i < iov.size()) {
-        const ssize_t n = writev(fd, &iov[i], (int)std::min<size_t>(iov.size() - i, 64));
-        if (n < 0) {
-            if (errno == EINTR) continue;
-            rc = fail(MIC_ERR_INVALID, "mic_png_write: writing %s: %s", path, strerror(errno));
-            break;
-        }
-        size_t left = (size_t)n;
-        while (i < iov.size() && left >= iov[i].iov_len) left -= iov[i++].iov_len;
-        if (i < iov.size() && left) {
-            iov[i].iov_base = static_cast<char *>(iov[i].iov_base) + left;
-            iov[i].iov_len -= left;
-        }
-    }
-    if (close(fd) != 0 && rc == MIC_OK) rc = fail(MIC_ERR_INVALID, "mic_png_write: closing %s: %s", path, strerror(errno));
-    return rc;
+    std::string err;
+    if (mic::png_write_file(pieces, path, &err) != 0) return fail(MIC_ERR_INVALID, "%s", err.c_str());
+    return MIC_OK;
+}
+
+extern "C" int mic_png_write_async(const char *path, const void *const *rows_host, int32_t width, int32_t height, int level,
+                                   int threads, int64_t *job) {
+    if (!job || !rows_host || !path || width <= 0 || height <= 0 || width > kMaxDim || height > kMaxDim)
+        return fail(MIC_ERR_INVALID, "mic_png_write_async: bad arguments");
+    for (int32_t y = 0; y < height; ++y)
+        if (!rows_host[y]) return fail(MIC_ERR_INVALID, "mic_png_write_async: row %d is null", y);
+    std::string err;
+    const int64_t id = mic::png_write_async(path, reinterpret_cast<const uint8_t *const *>(rows_host), width, height, level, threads, &err);
+    if (id < 0) return fail(MIC_ERR_NOMEM, "%s", err.c_str());
+    *job = id;
+    return MIC_OK;
+}
+
+extern "C" int mic_png_wait(int64_t job) {
+    std::string err;
+    const int rc = mic::png_wait(job, &err);
+    if (rc != 0) return fail(rc == -3 ? MIC_ERR_NOMEM : MIC_ERR_INVALID, "%s", err.c_str());
+    return MIC_OK;
 }
 
 extern "C" size_t mic_png_bound(int32_t width, int32_t height) { return mic::png_bound(width, height); }

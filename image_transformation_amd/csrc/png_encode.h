@@ -34,4 +34,14 @@ struct PngPieces {
 int png_encode_rows(const uint8_t *const *rows, int32_t w, int32_t h, int level, int threads, PngPieces *out,
                     std::string *err);
 
+// The pieces -> a file (one writev).  0, or -1 with *err.
+int png_write_file(const PngPieces &pieces, const char *path, std::string *err);
+
+// Encode + write on the library's own worker threads.  Returns a job id (> 0) at once, or -1 with *err; the row
+// pointers are copied, the PIXELS must stay valid until png_wait(id) has returned.  png_wait blocks until the job is
+// done and returns its status (0, or negative with *err); an id is waited for exactly once.
+int64_t png_write_async(const char *path, const uint8_t *const *rows, int32_t w, int32_t h, int level, int threads,
+                        std::string *err);
+int png_wait(int64_t id, std::string *err);
+
 }  // namespace mic

@@ -33,36 +33,47 @@ from . import png as mic_png
 
 class _PngWriter:
     """The artifacts are written by libmic's own PNG writer (png.py / csrc/png_encode.cpp: Sub/Up filtering, LZ77 +
-    dynamic Huffman, no PIL encoder) on a small thread pool while the next iteration is placed and composited: the C
-    call releases the GIL.  PIL's zlib level 6 was ~10 ms per 492x492 artifact, 8 artifacts per run -- 95 % of the
-    deterministic loop.  Each file is encoded on ONE pool thread (threads=1); big images split themselves."""
+    dynamic Huffman, no PIL encoder) on worker threads INSIDE the library (mic_png_write_async) while the next iteration
+    is placed and composited.  PIL's zlib level 6 was ~10 ms per 492x492 artifact, 8 artifacts per run -- 95 % of the
+    deterministic loop; Python worker threads around the C encoder still cost +0.8 ms per iteration in GIL hand-offs
+    on the main thread.  The JSON artifacts (a json.dumps each: GIL-bound whichever thread runs it) are formatted
+    after the last composite, while the PNGs are still being encoded."""
 
-    def __init__(self, workers: int = 8):
-        from concurrent.futures import ThreadPoolExecutor
-        self._pool = ThreadPoolExecutor(max_workers=workers)
+    def __init__(self):
         self._pending: List[Any] = []
+        self._texts: List[Tuple[Path, Any]] = []
 
     def save(self, image: Image.Image, path) -> None:
         # a draft of the bundles' size (492 x 492) is ~1.3 ms of encoding on one core and the last one saved is the
-        # tail of the whole run: two stripes halve it; big images split themselves further (threads=0)
+        # tail of the whole run: two stripes halve it; big images split themselves further
         px = image.size[0] * image.size[1]
-        threads = 0 if px >= (1 << 21) else (2 if px >= (1 << 17) else 1)
-        self._pending.append(self._pool.submit(mic_png.save, image, path, mic_png.DEFAULT_LEVEL, threads))
+        threads = 16 if px >= (1 << 21) else (2 if px >= (1 << 17) else 1)
+        self._pending.append(mic_png.save_async(image, path, mic_png.DEFAULT_LEVEL, threads))
 
     def text(self, path: Path, obj) -> None:
-        """json.dumps(obj, indent=2) -> path, off the caller's thread (the reference's layout / provenance / metadata
-        files: ~0.07 ms each to format, seven per run)."""
-        self._pending.append(self._pool.submit(lambda: path.write_text(json.dumps(obj, indent=2), encoding="utf-8")))
+        self._texts.append((path, obj))
 
     def copy(self, src, dst) -> None:
-        self._pending.append(self._pool.submit(shutil.copyfile, src, dst))
+        self._texts.append((Path(dst), Path(src)))
 
     def close(self) -> None:
+        first: Optional[BaseException] = None
         try:
-            for f in self._pending:
-                f.result()  # re-raise the first I/O error
-        finally:
-            self._pool.shutdown(wait=True)
+            for path, obj in self._texts:
+                if isinstance(obj, Path):
+                    shutil.copyfile(obj, path)
+                else:
+                    path.write_text(json.dumps(obj, indent=2), encoding="utf-8")
+        except BaseException as exc:  # noqa: BLE001  (still wait for every queued PNG: they read the images' memory)
+            first = exc
+        for p in self._pending:
+            try:
+                p.wait()
+            except BaseException as exc:  # noqa: BLE001
+                first = first or exc
+        self._pending.clear()
+        if first is not None:
+            raise first
 
 
 class _Steps:

@@ -79,6 +79,44 @@ def save(image, path, level: int = DEFAULT_LEVEL, threads: int = 0) -> None:
     del keep
 
 
+class PendingSave:
+    """A save queued on libmic's own worker threads (mic_png_write_async): wait() blocks until the file is written and
+    raises if it could not be.  Keeps the image alive until then."""
+    __slots__ = ("_job", "_keep")
+
+    def __init__(self, job: int, keep):
+        self._job, self._keep = job, keep
+
+    def wait(self) -> None:
+        if self._job is not None:
+            job, self._job = self._job, None
+            try:
+                _native.check(_native.lib().mic_png_wait(job))
+            finally:
+                self._keep = None
+
+    def __del__(self):  # never leave a job reading freed pixels behind
+        try:
+            self.wait()
+        except Exception:
+            pass
+
+
+def save_async(image, path, level: int = DEFAULT_LEVEL, threads: int = 1) -> PendingSave:
+    """save() without waiting: the encode + write run on worker threads inside libmic (no Python thread, no GIL
+    hand-offs on the caller's critical path).  Returns a PendingSave; call .wait() before relying on the file."""
+    kind, keep, ptr, W, H, stride = _source(image)
+    if kind != "rows":
+        arr = keep
+        table = np.empty(H, np.uint64)
+        table[:] = arr.ctypes.data + np.arange(H, dtype=np.uint64) * np.uint64(stride)
+        keep, ptr = (arr, table), table.ctypes.data
+    job = ctypes.c_int64()
+    _native.check(_native.lib().mic_png_write_async(os.fsencode(os.fspath(path)), _P(ptr), W, H, int(level), int(threads),
+                                                    ctypes.byref(job)))
+    return PendingSave(job.value, keep)
+
+
 def encode(image, level: int = DEFAULT_LEVEL, threads: int = 0) -> bytes:
     """`image` as PNG bytes."""
     kind, keep, ptr, W, H, stride = _source(image)

@@ -241,6 +241,13 @@ int mic_png_write(const char *path, const void *rgba_host, int32_t width, int32_
                   int level, int threads);
 int mic_png_write_rows(const char *path, const void *const *rows_host, int32_t width, int32_t height, int level,
                        int threads);
+/* The same on worker threads of the library's own: returns at once with *job; the PIXELS behind rows_host (the table
+ * itself is copied) must stay valid until mic_png_wait(job) has returned the job's status.  A caller that saves several
+ * artifacts while it goes on composing (run_macro_only's drafts, overlays, sheet: macro_placement_test.py:1428-1430,
+ * 1513-1514, 1699-1700) queues them and waits once at the end; no interpreter thread is involved.            */
+int mic_png_write_async(const char *path, const void *const *rows_host, int32_t width, int32_t height, int level,
+                        int threads, int64_t *job);
+int mic_png_wait(int64_t job);
 
 /* ---- layout: the integer half of render() -------------------------------------------------
  * Flex-DSL JSON text ({"root": {...}}) + cutout sizes + canvas size -> object ids and clamped boxes

@@ -16,7 +16,7 @@ static void mix(const uint8_t *p, size_t n) {
     for (size_t i = 0; i < n; ++i) g_hash = (g_hash ^ p[i]) * 1099511628211ull;
 }
 
-int main() {
+int main(int argc, char **argv) {
     uint32_t s = 12345;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
     const int sizes[][2] = {{1, 1}, {1, 777}, {999, 1}, {3, 3}, {4, 5}, {5, 4}, {15, 9}, {16, 9}, {17, 9}, {63, 7}, {64, 7}, {65, 7},
@@ -55,6 +55,29 @@ int main() {
                     ++n_ok;
                 }
         }
+    }
+    // the asynchronous writer: a burst of jobs on the library's worker threads, files into argv[1]
+    if (argc > 1) {
+        const int w = 300, h = 200;
+        std::vector<std::vector<uint8_t>> imgs(24, std::vector<uint8_t>((size_t)w * h * 4));
+        std::vector<std::vector<const uint8_t *>> tables(imgs.size());
+        std::vector<int64_t> ids;
+        for (size_t k = 0; k < imgs.size(); ++k) {
+            for (auto &b : imgs[k]) b = (k % 3 == 0) ? (uint8_t)rnd() : (uint8_t)(k * 7);
+            for (int y = 0; y < h; ++y) tables[k].push_back(imgs[k].data() + (size_t)y * w * 4);
+            std::string err;
+            const std::string path = std::string(argv[1]) + "/a" + std::to_string(k) + ".png";
+            const int64_t id = mic::png_write_async(path.c_str(), tables[k].data(), w, h, 1, 1 + (int)(k % 3), &err);
+            if (id <= 0) { printf("async submit failed: %s\n", err.c_str()); return 1; }
+            ids.push_back(id);
+        }
+        for (int64_t id : ids) {
+            std::string err;
+            if (mic::png_wait(id, &err) != 0) { printf("async job failed: %s\n", err.c_str()); return 1; }
+        }
+        std::string err;
+        if (mic::png_wait(ids[0], &err) == 0) { printf("a job was waited for twice\n"); return 1; }
+        n_ok += (int)ids.size();
     }
     printf("ok=%d hash=%016llx\n", n_ok, (unsigned long long)g_hash);
     return 0;

@@ -119,8 +119,11 @@ def test_png_encoder_under_asan_ubsan(tmp_path):
         pytest.skip("libasan not installed")
     assert r.returncode == 0, r.stderr[-2000:]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-    runs = [subprocess.run([out], capture_output=True, env=env, timeout=900) for _ in range(2)]
+    os.makedirs(tmp_path / "files", exist_ok=True)
+    runs = [subprocess.run([out, str(tmp_path / "files")], capture_output=True, env=env, timeout=900) for _ in range(2)]
     for r in runs:
         assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
         assert r.stdout.startswith(b"ok=") and b"ERROR" not in r.stderr and b"runtime error" not in r.stderr, r.stderr[-3000:]
     assert runs[0].stdout == runs[1].stdout  # deterministic bytes, whatever the thread scheduling
+    from PIL import Image
+    assert len(list((tmp_path / "files").glob("a*.png"))) == 24 and Image.open(tmp_path / "files" / "a5.png").size == (300, 200)

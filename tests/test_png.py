@@ -139,3 +139,24 @@ def test_save_like_pil_only_takes_png_names(tmp_path):
     mic_png.save_like_pil(im, tmp_path / "b.png", compress_level=9)  # explicit PIL options: PIL's encoder
     assert (tmp_path / "b.png").read_bytes() != mic_png.encode(im)
     assert np.array_equal(np.array(Image.open(tmp_path / "b.png")), np.array(im))
+
+
+def test_async_saves_on_the_library_threads(tmp_path):
+    """mic_png_write_async / mic_png_wait: many saves queued at once, each file identical to the synchronous writer's,
+    errors reported by wait(), an id waited for twice refused."""
+    from image_transformation_amd._native import MicError, lib
+    imgs = _images()
+    pend = []
+    for rep in range(3):
+        for name, a in imgs.items():
+            im = Image.fromarray(a, "RGBA") if rep % 2 == 0 else a
+            pend.append((name, a, tmp_path / f"{name}_{rep}.png", mic_png.save_async(im, tmp_path / f"{name}_{rep}.png", threads=1 + rep)))
+    for name, a, path, p in pend:
+        p.wait()
+        p.wait()  # idempotent on the Python object
+        assert np.array_equal(np.array(Image.open(path)), a), name
+    assert (tmp_path / "noise_0.png").read_bytes() == mic_png.encode(imgs["noise"], threads=1)
+    bad = mic_png.save_async(imgs["solid"], "/nonexistent-dir/x.png")
+    with pytest.raises(MicError, match="cannot open"):
+        bad.wait()
+    assert lib().mic_png_wait(987654321) != 0  # unknown job
