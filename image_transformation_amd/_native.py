@@ -109,7 +109,6 @@ SYMBOLS = {
                                          ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, _P, _P]),
     "mic_host_rows_solid": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(ctypes.c_uint8),
                                            ctypes.POINTER(ctypes.c_int)]),
-    "mic_upload_rows": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, _P, _P]),
     "mic_download": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P, _I32P]),
     "mic_download_wait": (ctypes.c_int, [_P, ctypes.c_int32]),
     "mic_png_bound": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),

@@ -153,16 +153,11 @@ def _upload(arr, ctx: _native.Context):
         pin = _pinned(H * W * 4)
         shape = (H, W, 4)
         if H * W * 4 >= (8 << 20):
-            # a large image: mic_upload_rows moves the rows out of Pillow's memory on a few threads of its own and
-            # enqueues the DMA of each 4 MB piece as soon as it sits in the pinned buffer (one C call: the Python-thread
-            # version of this pipeline lost to GIL hand-offs what the overlap gained)
-            tab = _pilmem.row_table(arr)
-            if tab is not None:
-                dev = torch.empty(shape, dtype=torch.uint8, device=ctx.torch_device)
-                with _device_guard(ctx):
-                    _native.check(_native.lib().mic_upload_rows(ctx.handle, _P(tab[0]), W, H, _P(pin.data_ptr()),
-                                                                _P(dev.data_ptr()), _P(_stream_of(ctx))))
-                _keep_until_stream_passes(pin, dev)
+            # a large image: the DMA of each few-MB piece starts as soon as that piece sits in the pinned buffer, while
+            # the worker threads are still moving the next ones out of Pillow's memory
+            dev = torch.empty(shape, dtype=torch.uint8, device=ctx.torch_device)
+            flat = dev.view(-1)
+            if _pilmem.copy_to_pipelined(arr, pin.data_ptr(), lambda o, k: flat[o:o + k].copy_(pin[o:o + k], non_blocking=True)):
                 return dev
         if not _pilmem.copy_to(arr, pin.data_ptr()):
             pin.numpy()[:] = np.asarray(arr, dtype=np.uint8).reshape(-1)
@@ -178,13 +173,6 @@ def _upload(arr, ctx: _native.Context):
 
 
 _RESULT_COPY = os.environ.get("MIC_RESULT_COPY") == "1"
-
-
-def _keep_until_stream_passes(pin, dev) -> None:
-    """A pinned staging buffer that copies enqueued OUTSIDE torch read (mic_upload_rows): one more, 4-byte, copy from it
-    through torch on the same stream makes torch's caching host allocator record an event for the block behind them
-    all, so that the block is not handed out again before the stream has passed the copies."""
-    dev.view(-1)[:4].copy_(pin[:4], non_blocking=True)
 
 
 def _to_pil(canvas_dev, view: bool = False) -> Image.Image:

@@ -16,10 +16,8 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
-#include <atomic>
 #include <map>
 #include <memory>
-#include <thread>
 #include <mutex>
 #include <new>
 #include <tuple>
@@ -1675,59 +1673,6 @@ extern "C" int mic_host_rows_solid(const void *const *rows_host, int32_t width, 
         if (diff) return MIC_OK;
     }
     *is_solid = 1;
-    return MIC_OK;
-}
-
-extern "C" int mic_upload_rows(mic_ctx *ctx, const void *const *rows_host, int32_t width, int32_t height, void *pinned_host,
-                               void *dst_dev, void *stream_v) {
-    CTX_ENTER(ctx);
-    if (!rows_host || !pinned_host || !dst_dev || width <= 0 || height <= 0 || width > kMaxDim || height > kMaxDim)
-        return fail(MIC_ERR_INVALID, "mic_upload_rows: bad arguments");
-    hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    if (int rc = adopt_stream(ctx, stream)) return rc;
-    const size_t line = (size_t)width * 4, total = line * (size_t)height;
-    const int rows_per_piece = (int)std::max<size_t>(1, ((size_t)4 << 20) / line);
-    const int n_pieces = (height + rows_per_piece - 1) / rows_per_piece;
-    const int n_threads = std::min(4, n_pieces);
-    std::vector<std::atomic<int>> done((size_t)n_pieces);
-    for (auto &d : done) d.store(0, std::memory_order_relaxed);
-    std::atomic<int> next{0};
-    uint8_t *stage = static_cast<uint8_t *>(pinned_host);
-    auto work = [&]() {
-        for (int p; (p = next.fetch_add(1)) < n_pieces;) {
-            const int y0 = p * rows_per_piece, y1 = std::min(height, y0 + rows_per_piece);
-            for (int y = y0; y < y1; ++y) memcpy(stage + (size_t)y * line, rows_host[y], line);
-            done[(size_t)p].store(1, std::memory_order_release);
-        }
-    };
-    std::vector<std::thread> pool;
-    try {
-        for (int t = 1; t < n_threads; ++t) pool.emplace_back(work);
-    } catch (...) {  // no more threads: this one moves everything
-    }
-    hipError_t e = hipSuccess;
-    int issued = 0;
-    // this thread alternates: move a piece itself when none is ready, issue the DMA of every piece that is
-    while (issued < n_pieces && e == hipSuccess) {
-        if (!done[(size_t)issued].load(std::memory_order_acquire)) {
-            const int p = next.fetch_add(1);
-            if (p < n_pieces) {
-                const int y0 = p * rows_per_piece, y1 = std::min(height, y0 + rows_per_piece);
-                for (int y = y0; y < y1; ++y) memcpy(stage + (size_t)y * line, rows_host[y], line);
-                done[(size_t)p].store(1, std::memory_order_release);
-            } else {
-                std::this_thread::yield();
-            }
-            continue;
-        }
-        const size_t off = (size_t)issued * rows_per_piece * line;
-        const size_t n = std::min(total - off, (size_t)rows_per_piece * line);
-        e = hipMemcpyAsync(static_cast<uint8_t *>(dst_dev) + off, stage + off, n, hipMemcpyHostToDevice, stream);
-        ++issued;
-    }
-    next.store(n_pieces);  // (on an error: the workers stop taking pieces)
-    for (auto &th : pool) th.join();
-    if (e != hipSuccess) return fail(MIC_ERR_HIP, "mic_upload_rows: %s", hipGetErrorString(e));
     return MIC_OK;
 }
 

@@ -216,13 +216,6 @@ int mic_contact_sheet(mic_ctx *ctx, mic_atlas *atlas, int32_t n, const int32_t *
  * (macro_placement_test.py:1510); a one-colour background is synthesised in-kernel instead of uploaded.      */
 int mic_host_rows_solid(const void *const *rows_host, int32_t width, int32_t y0, int32_t y1, const uint8_t rgba[4],
                         int *is_solid);
-/* mic_upload_rows: a host image given by its row table (a PIL image keeps large images in several blocks) -> device,
- * through the caller's PINNED staging buffer (width * height * 4 bytes): worker threads of the call move the rows into
- * the staging buffer in pieces of a few MB and the host -> device copy of each piece is enqueued on `stream` as soon
- * as it is there -- the DMA starts after the first piece instead of after the last.  Returns when everything is
- * enqueued; the staging buffer must stay valid until the stream has passed the copies.                        */
-int mic_upload_rows(mic_ctx *ctx, const void *const *rows_host, int32_t width, int32_t height, void *pinned_host,
-                    void *dst_dev, void *stream);
 /* mic_download: enqueue a device -> pinned-host copy on `stream` and mark its end with an event of its own;
  * *ticket names it.  mic_download_wait(ticket) blocks the calling thread until THAT copy has landed (an event wait,
  * not a stream drain; other threads keep enqueueing meanwhile).  A ticket is waited for at most once.

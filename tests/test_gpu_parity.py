@@ -706,27 +706,3 @@ def test_layer_records_in_kernel_arguments_boundary(gpu):
             plan = CompositeBatch(atlas, [SolidCanvas((W, H), syn.SOLID_BG)], [rows])
             for _ in range(2):
                 assert np.array_equal(plan.run()[0].cpu().numpy(), want), (n, resample, "plan")
-
-
-def test_large_pil_background_upload_in_pieces(gpu):
-    """A PIL background that is not one colour and large enough for mic_upload_rows (rows moved out of Pillow's blocks by
-    the call's own threads, DMA enqueued piece by piece): 4K and an odd 4399-wide canvas, several calls in a row (the
-    pinned staging block must not be recycled early), equal to the oracle."""
-    from image_transformation_amd.compositor import composite, render
-    syn = cases.synthetic
-    rng = np.random.default_rng(909)
-    objs = syn.make_cutouts(6, (200, 500), (150, 400), seed=910, alpha_mode="soft")
-    pil_objs = {k: _img(v) for k, v in objs.items()}
-    for (W, H) in ((3840, 2160), (4399, 1885)):
-        for rep in range(3):
-            bg = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
-            pl = [{"object_id": k, "box": [int(rng.integers(-50, W - 100)), int(rng.integers(-50, H - 100)), 0, 0]} for k in objs]
-            for p in pl:
-                sh, sw = objs[p["object_id"]].shape[:2]
-                p["box"][2], p["box"][3] = p["box"][0] + sw, p["box"][1] + sh
-            want = oracle.composite(bg, objs, pl)
-            got = np.array(composite(_img(bg), pil_objs, pl))
-            assert np.array_equal(got, want), (W, H, rep)
-            if rep == 0:
-                got_t = render({"placements": pl}, pil_objs, _img(bg), as_tensor=True).cpu().numpy()
-                assert np.array_equal(got_t, want)
