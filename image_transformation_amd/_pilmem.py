@@ -143,28 +143,6 @@ def copy_to(img: Image.Image, dst_addr: int) -> bool:
     return True
 
 
-def copy_to_pipelined(img: Image.Image, dst_addr: int, on_piece) -> bool:
-    """copy_to() for large images with a hook: the image is moved in pieces of a few MB on the worker threads and
-    on_piece(byte_offset, nbytes) is called, in order, as soon as everything up to that piece's end has landed --
-    the caller starts the host -> device DMA of a piece while the next ones are still being memmove'd (a 33 MB image:
-    the upload begins after the first 4 MB instead of after all of them)."""
-    runs = row_runs(img)
-    if runs is None:
-        return False
-    jobs = []
-    off = 0
-    for addr, n in runs:
-        for p in range(0, n, _PARALLEL_BYTES):
-            k = min(_PARALLEL_BYTES, n - p)
-            jobs.append((dst_addr + off + p, addr + p, k, off + p))
-        off += n
-    futures = [_workers().submit(ctypes.memmove, d, s, k) for d, s, k, _ in jobs]
-    for f, (_, _, k, o) in zip(futures, jobs):
-        f.result()
-        on_piece(o, k)
-    return True
-
-
 def same_pixels(a: Image.Image, b: Image.Image) -> bool:
     """Do two RGBA images hold the same size and bytes?  memcmp over Pillow's own rows (no tobytes() copies); False
     also when either image's memory cannot be located."""

@@ -152,13 +152,6 @@ def _upload(arr, ctx: _native.Context):
         W, H = arr.size
         pin = _pinned(H * W * 4)
         shape = (H, W, 4)
-        if H * W * 4 >= (8 << 20):
-            # a large image: the DMA of each few-MB piece starts as soon as that piece sits in the pinned buffer, while
-            # the worker threads are still moving the next ones out of Pillow's memory
-            dev = torch.empty(shape, dtype=torch.uint8, device=ctx.torch_device)
-            flat = dev.view(-1)
-            if _pilmem.copy_to_pipelined(arr, pin.data_ptr(), lambda o, k: flat[o:o + k].copy_(pin[o:o + k], non_blocking=True)):
-                return dev
         if not _pilmem.copy_to(arr, pin.data_ptr()):
             pin.numpy()[:] = np.asarray(arr, dtype=np.uint8).reshape(-1)
     else:

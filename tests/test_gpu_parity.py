@@ -706,3 +706,24 @@ def test_layer_records_in_kernel_arguments_boundary(gpu):
             plan = CompositeBatch(atlas, [SolidCanvas((W, H), syn.SOLID_BG)], [rows])
             for _ in range(2):
                 assert np.array_equal(plan.run()[0].cpu().numpy(), want), (n, resample, "plan")
+
+
+def test_large_pil_backgrounds(gpu):
+    """A PIL background that is not one colour at full size (uploaded through the pinned staging buffer): 4K and an odd
+    4399-wide canvas, several calls in a row, composite() and render(as_tensor=True), equal to the oracle."""
+    from image_transformation_amd.compositor import composite, render
+    syn = cases.synthetic
+    rng = np.random.default_rng(909)
+    objs = syn.make_cutouts(6, (200, 500), (150, 400), seed=910, alpha_mode="soft")
+    pil_objs = {k: _img(v) for k, v in objs.items()}
+    for (W, H) in ((3840, 2160), (4399, 1885)):
+        for rep in range(2):
+            bg = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+            pl = [{"object_id": k, "box": [int(rng.integers(-50, W - 100)), int(rng.integers(-50, H - 100)), 0, 0]} for k in objs]
+            for p in pl:
+                sh, sw = objs[p["object_id"]].shape[:2]
+                p["box"][2], p["box"][3] = p["box"][0] + sw, p["box"][1] + sh
+            want = oracle.composite(bg, objs, pl)
+            assert np.array_equal(np.array(composite(_img(bg), pil_objs, pl)), want), (W, H, rep)
+            if rep == 0:
+                assert np.array_equal(render({"placements": pl}, pil_objs, _img(bg), as_tensor=True).cpu().numpy(), want)

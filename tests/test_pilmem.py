@@ -90,25 +90,6 @@ def test_row_table_and_exact_solid_scan():
     assert _pilmem.solid_colour(Image.new("RGBA", (300, 200), (1, 2, 3, 4))) == (1, 2, 3, 4)
 
 
-def test_pipelined_copy_reports_pieces_in_order_and_covers_everything():
-    rng = np.random.default_rng(11)
-    a = rng.integers(0, 256, (2160, 3840, 4), dtype=np.uint8)
-    big = Image.new("RGBA", (3840, 2160))
-    big.paste(Image.fromarray(a, "RGBA"))  # several memory blocks
-    dst = np.zeros(a.size, np.uint8)
-    seen = []
-
-    def on_piece(off, n):
-        # everything up to off + n must already be in place when the hook runs (the DMA would start now)
-        assert np.array_equal(dst[off:off + n], a.reshape(-1)[off:off + n])
-        seen.append((off, n))
-
-    assert _pilmem.copy_to_pipelined(big, dst.ctypes.data, on_piece)
-    assert [o for o, _ in seen] == sorted(o for o, _ in seen) and seen[0][0] == 0
-    assert sum(n for _, n in seen) == a.size and all(seen[i][0] + seen[i][1] == seen[i + 1][0] for i in range(len(seen) - 1))
-    assert np.array_equal(dst.reshape(a.shape), a)
-
-
 def test_same_pixels_is_an_exact_byte_comparison():
     rng = np.random.default_rng(12)
     for size in ((7, 5), (492, 492), (2300, 2100)):
