@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_select_kernel(const Me
 // scratch_dev: 2 * kMedianMaxBatch slots of kMedianSlotWords (a double buffer), zero on entry of the first call; the
 // launcher alternates halves with *phase and hands the half used by the previous call to this one for clearing.
 hipError_t launch_median_batch(int k, const MedianView *views, uint32_t *const *out_rgba_dev, uint32_t *scratch_dev,
-                               MedianState *state, bool two_launches, hipStream_t stream) {
+                               MedianState *state, int two_launches, hipStream_t stream) {
     if (k <= 0 || k > kMedianMaxBatch) return hipErrorInvalidValue;
     MedianBatch B{};
     const uint32_t half = (uint32_t)kMedianMaxBatch * (uint32_t)kMedianSlotWords;
@@ -342,7 +342,11 @@ hipError_t launch_median_batch(int k, const MedianView *views, uint32_t *const *
     bool strided = false;
     for (int i = 0; i < k; ++i) strided |= B.img[i].stride != B.img[i].w;
     const dim3 grid(grid_x, (unsigned)k), block(64 * kHistWaves);
-    if (two_launches) {
+    // Large images (a grid of >= 384 blocks: 4K and up) take the two-launch form: there the kernel boundary + a
+    // one-block select launch is ~1 us cheaper than the ticket + the last block's read-back under load (4K 16.1 vs
+    // 17.2 us, 8K 31.8 vs 32.1); at the bundles' sizes the one-launch form is 0.6 us ahead
+    // (profiles/r03_median_experiments.txt).  MIC_MEDIAN_TWO_LAUNCHES=1 / =0 forces either form.
+    if (two_launches == 1 || (two_launches < 0 && grid_x >= 384u)) {
         if (strided) hipLaunchKernelGGL((median_kernel<false, true>), grid, block, 0, stream, B);
         else hipLaunchKernelGGL((median_kernel<false, false>), grid, block, 0, stream, B);
         hipLaunchKernelGGL(median_select_kernel, dim3((unsigned)k), block, 0, stream, B);

@@ -175,7 +175,7 @@ struct mic_ctx {
     uint32_t *median_scratch = nullptr;  // device: two sets of histogram slots (a double buffer) + kMedianMaxBatch result words
     MedianState median_state;            // which half the next call works in, what the previous one left to clear
     bool layer_args = true;              // MIC_LAYER_ARGS=0: single-canvas launches read their layer records from the device table
-    bool median_two_launches = false;    // MIC_MEDIAN_TWO_LAUNCHES=1: histogram kernel + select kernel (measurement aid)
+    int median_two_launches = -1;        // MIC_MEDIAN_TWO_LAUNCHES=1 / 0: force the two-launch / one-launch median (-1: by image size)
     uint32_t *gradient_table = nullptr;  // device: fill_gradient's per-position colours (allocated on first use)
     uint32_t *median_host = nullptr;     // pinned
     hipStream_t last_stream = nullptr;
@@ -249,7 +249,7 @@ extern "C" int mic_create(int device, mic_ctx **out) {
         }
     }
     if (const char *la = getenv("MIC_LAYER_ARGS")) ctx->layer_args = atoi(la) != 0;
-    if (const char *tl = getenv("MIC_MEDIAN_TWO_LAUNCHES")) ctx->median_two_launches = atoi(tl) != 0;
+    if (const char *tl = getenv("MIC_MEDIAN_TWO_LAUNCHES")) ctx->median_two_launches = atoi(tl) != 0 ? 1 : 0;
     e = hipMalloc(&ctx->median_scratch, (kMedianScratchWords + 64) * sizeof(uint32_t));
     // zeroed once: every median call clears the half of the double buffer the call before it used
     if (e == hipSuccess) e = hipMemset(ctx->median_scratch, 0, (kMedianScratchWords + 64) * sizeof(uint32_t));

@@ -196,6 +196,6 @@ struct MedianState {
     uint32_t prev_words = 0;  // words of the other half the previous call used
 };
 hipError_t launch_median_batch(int k, const MedianView *views, uint32_t *const *out_rgba_dev, uint32_t *scratch_dev,
-                               MedianState *state, bool two_launches, hipStream_t stream);
+                               MedianState *state, int two_launches /* 1, 0, or -1 = by size */, hipStream_t stream);
 
 }  // namespace mic
