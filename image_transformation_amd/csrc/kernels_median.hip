@@ -25,6 +25,7 @@
 // case with readfirstlane/__ballot and lets one lane add the population count.  Otherwise (noisy
 // regions, mostly distinct bins) every lane issues its own LDS atomics.
 #include <algorithm>
+#include <cstdlib>
 
 #include "mic_internal.h"
 
@@ -35,7 +36,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kHistWaves = 16;
 constexpr int kChunks = 4;                      // 16-byte loads a lane keeps in flight per trip
 constexpr size_t kTripPx = (size_t)256 * kChunks;  // pixels one wave takes per trip (4 KiB)
-constexpr unsigned kMaxBlocks = 512;
+constexpr unsigned kMaxBlocks = 256;  // one block of 16 waves per CU (round 3 sweep: 512 -> 256: 4K 17.2 -> 16.3 us, 8K 32.2 -> 31.3; 384 / 320 / 192 leave CUs unevenly loaded: 8K 36-41 us)
 // LDS histogram replicas, interleaved so the kCopies words of one bin sit in kCopies different banks:
 // word = bin_index * kCopies + (lane & (kCopies - 1)).  64 lanes hitting one bin serialise 64/kCopies
 // deep instead of 64.
@@ -328,11 +329,16 @@ hipError_t launch_median_batch(int k, const MedianView *views, uint32_t *const *
         I.n_px = (uint64_t)v.w * v.h;
         I.w = v.w;
         I.stride = v.stride_px;
-        // one trip (4 KiB) per wave before a block takes a second one: a 4K image then runs on 506 blocks (every
-        // CU, two deep) instead of 127 (half the CUs idle), a 492 x 492 bundle background on 15 instead of 4
+        // one trip (4 KiB) per wave before a block takes a second one, up to one block per CU: a 4K image runs on
+        // 256 blocks x 2 trips, a 492 x 492 bundle background on 15 blocks
         const size_t per_block = kTripPx * kHistWaves;  // pixels per block per trip
         size_t blocks = (I.n_px + per_block - 1) / per_block;
-        blocks = std::min<size_t>(std::max<size_t>(blocks, 1), kMaxBlocks);
+        static const size_t max_blocks = [] {  // MIC_MEDIAN_MAX_BLOCKS: tuning knob (default kMaxBlocks)
+            const char *e = getenv("MIC_MEDIAN_MAX_BLOCKS");
+            const long v = e ? atol(e) : 0;
+            return v > 0 && v <= (long)kMaxBlocks ? (size_t)v : (size_t)kMaxBlocks;
+        }();
+        blocks = std::min<size_t>(std::max<size_t>(blocks, 1), max_blocks);
         I.blocks = (uint32_t)blocks;
         I.copies = (uint32_t)median_copies((unsigned)blocks);
         grid_x = std::max(grid_x, (unsigned)blocks);
@@ -342,11 +348,11 @@ hipError_t launch_median_batch(int k, const MedianView *views, uint32_t *const *
     bool strided = false;
     for (int i = 0; i < k; ++i) strided |= B.img[i].stride != B.img[i].w;
     const dim3 grid(grid_x, (unsigned)k), block(64 * kHistWaves);
-    // Large images (a grid of >= 384 blocks: 4K and up) take the two-launch form: there the kernel boundary + a
-    // one-block select launch is ~1 us cheaper than the ticket + the last block's read-back under load (4K 16.1 vs
-    // 17.2 us, 8K 31.8 vs 32.1); at the bundles' sizes the one-launch form is 0.6 us ahead
-    // (profiles/r03_median_experiments.txt).  MIC_MEDIAN_TWO_LAUNCHES=1 / =0 forces either form.
-    if (two_launches == 1 || (two_launches < 0 && grid_x >= 384u)) {
+    // The two-launch form (kernel boundary + a one-block select launch instead of the ticket + the last block's
+    // read-back) is the measured alternative, MIC_MEDIAN_TWO_LAUNCHES=1: with one block per CU it is 0.6 us ahead at 4K
+    // (15.7 vs 16.3 us), level at 8K (31.8 vs 31.3), 0.6-1.1 us behind at the bundles' sizes and at 1080p
+    // (profiles/r03_median_experiments.txt) -- the one-launch form is the default everywhere.
+    if (two_launches == 1) {
         if (strided) hipLaunchKernelGGL((median_kernel<false, true>), grid, block, 0, stream, B);
         else hipLaunchKernelGGL((median_kernel<false, false>), grid, block, 0, stream, B);
         hipLaunchKernelGGL(median_select_kernel, dim3((unsigned)k), block, 0, stream, B);
