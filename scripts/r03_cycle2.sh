@@ -1,5 +1,5 @@
 #!/bin/bash
-run() { python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
-import json,sys; r=json.loads(sys.stdin.read()); print('   ms_per_step', r['ms_per_step'], 'kernel_ms', r['roofline']['kernel_ms'])"; }
-echo "baseline"; run; run
-for v in SALU_64 SALU_128 VALU_64 VALU_128; do echo "$v"; MIC_LIB=$PWD/scripts/libmic_exp_$v.bin run; done
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_c_abi.py -m gpu -x -q 2>&1 | tail -2
+run() { python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extras 2>/dev/null | python -c "
+import json,sys; r=json.loads(sys.stdin.read()); print('   ms_per_step', r['ms_per_step'], 'kernel_ms', r['roofline']['kernel_ms'], 'c4', r['c4_strong']['ms_per_step'] if 'c4_strong' in r else None)"; }
+for i in 1 2 3; do echo "new"; run; echo "prev"; MIC_LIB=$PWD/scripts/libmic_prev.bin run; done
