@@ -1,5 +1,2 @@
 #!/bin/bash
-# ad-hoc GPU cycle (rewritten per experiment): GPU parity tests, then whatever is being measured
-mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/cyc_tests.log 2>&1
-tail -2 gpurun_out/cyc_tests.log
+for i in 1 2; do for u in 0 6500 8000 9500 10600 12000; do MIC_N=100 MIC_ALPHAS=soft,binary MIC_RS_UNIT_PX=$u timeout -k 10 120 python scripts/time_placements.py || exit 1; done; done
