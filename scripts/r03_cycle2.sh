@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of the marching resample kernel: shipped library (scripts/var_old.bin) vs the tree's, on the bench's own legs
+# A/B on the bench's own legs: a previous build (scripts/var_old.bin: build the commit to compare against with scripts/build_variant.sh from a
+# checkout of it) vs the tree's library
 mkdir -p gpurun_out
 timeout -k 10 500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_c_abi.py tests/test_gpu_march.py -m gpu -x -q > gpurun_out/cyc_tests.log 2>&1
 tail -1 gpurun_out/cyc_tests.log
