@@ -890,7 +890,7 @@ def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_
             "alpha": amode, "ms_per_canvas_wall": round(e2 / 10 * 1e3, 3), "resample_ms": round(r2, 4),
             "composite_ms": round(c2, 4), "Mpixels_per_s": round(W * H * 10 / e2 / 1e6, 1),
             "composite_roofline_frac": frac(plan_bytes(ps), c2),
-            "resample_roofline": {"bound": "instruction issue (VALU + scalar), not hbm: profiles/r02_resample_experiments.txt",
+            "resample_roofline": {"bound": "instruction issue in the loop (84 % of vector issue at full residency), residency over the launch: profiles/r03_resample_experiments.txt",
                                   "algorithmic_bytes": rs_bytes, "achieved_GBps": round(rs_bytes / (r2 * 1e-3) / 1e9, 1),
                                   "frac_of_hbm_peak": frac(rs_bytes, r2)}}
         if amode == "soft":
