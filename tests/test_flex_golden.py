@@ -154,3 +154,70 @@ def test_reference_layout_constraints_test_restated():
     tw, th = compute_canvas_size((1920, 1080), "9:16", quiet=True)
     assert abs(tw / th - parse_ratio("9:16")) < 0.02
     assert abs(tw * th - 1920 * 1080) / (1920 * 1080) < 0.02
+
+
+def _random_tree(rng, ids, depth=0):
+    """A random Flex tree over the DSL the reference's placer reads (macro_placement_test.py:637-964): nested
+    containers, every justify / align spelling (unknown ones included: they fall back), gaps and paddings of every
+    accepted form, objects with padding / pin / offset / stick_to, unknown and repeated ids."""
+    node = {"type": "flex"}
+    if rng.random() < 0.9:
+        node["direction"] = rng.choice(["row", "column", "row", "column", "diagonal"])
+    if rng.random() < 0.7:
+        node["justify"] = rng.choice(["start", "center", "end", "space-between", "space-around", "space-evenly", "stretch", "weird"])
+    if rng.random() < 0.7:
+        node["align"] = rng.choice(["start", "center", "end", "stretch", "baseline"])
+    if rng.random() < 0.6:
+        node["gap_px"] = rng.choice([0, 1, 7, 16, 33, -4, 250, 3.7, "12", True, "1_0"])  # ("1_0": int() takes it, the native placer declines)
+    if rng.random() < 0.5:
+        node["padding_px"] = rng.choice([0, 2, 9, 24, -3, 120, 5.2, "8", False])
+    kids = []
+    for _ in range(rng.randint(0, 5)):
+        if depth < 3 and rng.random() < 0.3:
+            kids.append(_random_tree(rng, ids, depth + 1))
+            continue
+        obj = {"object_id": rng.choice(ids + [ids[0], 99, str(ids[-1])])}
+        if rng.random() < 0.3:
+            obj["padding_px"] = rng.choice([3, 0, 11, {"left": 4, "top": 2}, {"right": 9, "bottom": 1, "left": 0, "top": 5}])
+        if rng.random() < 0.2:
+            obj["pin"] = rng.choice([{"horizontal": "start"}, {"vertical": "end", "horizontal": "center"}, {}])
+        if rng.random() < 0.2:
+            obj["offset_px"] = rng.choice([{"x": 5}, {"y": -7, "x": 2}, {}])
+        if rng.random() < 0.2:
+            obj["stick_to"] = rng.choice([{"edges": ["left"]}, {"edges": ["top", "right"], "margin_px": 6}])
+        if rng.random() < 0.04:  # malformed object fields: the reference raises ValueError, the native placer declines
+            obj.update(rng.choice([{"pin": {"horizontal": "middle"}}, {"pin": "start"}, {"offset_px": {"x": 1.5}},
+                                   {"offset_px": {"z": 1}}, {"stick_to": {"edges": ["left", "right"]}},
+                                   {"stick_to": {"edges": []}}, {"stick_to": {"edges": ["top"], "margin_px": -1}},
+                                   {"padding_px": {"inner": 3}}, {"padding_px": -2}]))
+        kids.append(obj)
+    if kids or rng.random() < 0.8:
+        node["children"] = kids
+    return node
+
+
+def test_native_placer_vs_the_mirror_on_fresh_random_trees():
+    """Differential fuzz of mic_flex_place (csrc/flex_place.cpp) against flex.py, which the reference's own boxes pin
+    (tests above): 3000 seeded random trees the fixtures do not contain.  Whenever the native placer answers, its
+    boxes are flex.py's; whenever flex.py raises (the reference's ValueErrors), the native placer must decline."""
+    import random
+
+    rng = random.Random(20261004)
+    answered = 0
+    for n in range(3000):
+        ids = rng.sample(range(1, 40), rng.randint(1, 6))
+        sizes = {i: (rng.randint(1, 700), rng.randint(1, 500)) for i in ids}
+        canvas = (rng.choice([1, 64, 492, 1080, 1920, 3840]), rng.choice([1, 48, 492, 1350, 1080, 2160]))
+        layout = {"root": _random_tree(rng, ids)}
+        try:
+            want = [(int(p["object_id"]), *p["box"]) for p in flex.layout_to_placements(copy.deepcopy(layout), sizes, canvas)]
+        except Exception:  # noqa: BLE001  (whatever the mirror raises, the native placer leaves the tree to it)
+            assert flex.native_boxes(layout, sizes, canvas) is None, (n, layout)
+            continue
+        got = flex.native_boxes(layout, sizes, canvas)
+        if got is None:
+            continue
+        answered += 1
+        assert got == want, (n, layout, sizes, canvas)
+        assert flex.native_boxes(json.dumps(layout), sizes, canvas) == want, n
+    assert answered >= 2000, answered  # the native placer takes the great majority itself
