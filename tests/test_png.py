@@ -160,3 +160,31 @@ def test_async_saves_on_the_library_threads(tmp_path):
     with pytest.raises(MicError, match="cannot open"):
         bad.wait()
     assert lib().mic_png_wait(987654321) != 0  # unknown job
+
+
+def test_png_seeded_sweep_of_shapes_and_contents():
+    """120 seeded images the fixed kinds above do not contain: every size class from 1 px to a few hundred on each
+    side (stripe boundaries fall everywhere), five content classes, every level / thread setting -- each decoded by
+    Pillow and its stream structure checked."""
+    rng = np.random.default_rng(20261004)
+    for n in range(120):
+        h = int(rng.choice([1, 2, 3, 7, 16, 17, 63, 64, 65, 200, 333]))
+        w = int(rng.choice([1, 2, 5, 31, 32, 33, 127, 128, 129, 492, 700]))
+        kind = n % 5
+        if kind == 0:
+            a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        elif kind == 1:  # few colours, long runs
+            a = rng.integers(0, 3, (h, w, 1), dtype=np.uint8).repeat(4, axis=2) * 85
+        elif kind == 2:  # smooth gradients (Sub / Up filters matter)
+            yy, xx = np.mgrid[0:h, 0:w]
+            a = np.stack([(xx + yy) % 256, (2 * xx) % 256, (3 * yy) % 256, np.full_like(xx, 255)], axis=2).astype(np.uint8)
+        elif kind == 3:  # a cutout: transparent margins around noise
+            a = np.zeros((h, w, 4), np.uint8)
+            a[h // 4:h - h // 4, w // 4:w - w // 4] = rng.integers(0, 256, (h - 2 * (h // 4), w - 2 * (w // 4), 4), dtype=np.uint8)
+        else:  # a repeated row (matches at distance = one row)
+            a = np.tile(rng.integers(0, 256, (1, w, 4), dtype=np.uint8), (h, 1, 1))
+        level, threads = int(rng.integers(0, 2)), int(rng.choice([0, 1, 2, 5]))
+        data = mic_png.encode(a, level=level, threads=threads)
+        _check_structure(data, a.shape)
+        back = np.asarray(Image.open(io.BytesIO(data)).convert("RGBA"))
+        assert back.shape == a.shape and np.array_equal(back, a), (n, h, w, kind, level, threads)
