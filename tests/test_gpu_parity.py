@@ -430,6 +430,35 @@ def test_properties_full_size(gpu):
     assert not torch.equal(rev, full)
 
 
+def test_properties_full_size_lanczos_batches(gpu):
+    """Size-independent properties of the placements mode (Pillow-exact LANCZOS layers) at the bench size:
+    - a batch of canvases in ONE call (one resample launch over every canvas' layers, one composite launch over every
+      canvas' pages) equals the same canvases one call each;
+    - splitting a placement list into two successive composites equals one composite, resampled layers included;
+    - a persistent plan run twice, and run into a second set of outputs, repeats itself bit for bit."""
+    import torch
+    from image_transformation_amd.compositor import Atlas, CompositeBatch, SolidCanvas, composite_device, coerce_placements
+    syn = cases.synthetic
+    (W, H), objs, pl = syn.placements_workload(3840, 2160, 32, 3, "soft")
+    atlas = Atlas(objs)
+    sets = [pl] + syn.placement_sets(objs, W, H, 3, 3)
+    rows = [coerce_placements(atlas, q) for q in sets]
+    solid = SolidCanvas((W, H), syn.SOLID_BG)
+    together = composite_device(atlas, [solid] * len(rows), rows)
+    for k, r in enumerate(rows):
+        alone = composite_device(atlas, [solid], [r])[0]
+        assert torch.equal(together[k], alone), k
+    first = composite_device(atlas, [solid], [rows[1][:11]])[0]
+    second = composite_device(atlas, [first], [rows[1][11:]])[0]
+    assert torch.equal(second, together[1])
+    plan = CompositeBatch(atlas, [solid] * len(rows), rows)
+    a, b = plan.alloc_outputs(), plan.alloc_outputs()
+    plan.run(a); plan.run(b); plan.run(a)
+    torch.cuda.synchronize()
+    for k in range(len(rows)):
+        assert torch.equal(a[k], together[k]) and torch.equal(b[k], together[k]), k
+
+
 def test_ragged_and_extreme_shapes(gpu):
     """1-pixel canvases/objects, widths that are not multiples of 4 or 256, > 64 layers per canvas."""
     from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
