@@ -163,3 +163,27 @@ def test_march_many_layers_overhang_vs_oracle(forced):
             assert np.array_equal(got, want), ((W, H), filt, st, pl)
             assert st["marched_layers"] >= 8, st
     assert lib.mic_atlas_destroy(atlas) == 0
+
+
+def test_march_every_colour_alpha_pair(forced):
+    """Every (colour, alpha) pair through the marching kernel's premultiply (planarize_kernel) -> digit-chain passes
+    -> unpremultiply: a 256 x 256 source whose pixel (x, y) is colour x at alpha y (the other channels permuted
+    values), repeated 2 x 2 so that every pair also sits next to its opposite, resized to shapes on both sides of 1."""
+    lib, ctx, nat = forced
+    x = np.arange(256, dtype=np.uint8)
+    c, a = np.meshgrid(x, x)
+    quad = np.stack([c, 255 - c, (c.astype(np.uint16) * 7 & 255).astype(np.uint8), a], axis=2)
+    top = np.concatenate([quad, quad[:, ::-1]], axis=1)
+    src = np.ascontiguousarray(np.concatenate([top, top[::-1]], axis=0))  # 512 x 512
+    objs = {1: src}
+    atlas = _atlas(lib, ctx, objs)
+    marched = 0
+    for dw, dh in [(512, 513), (513, 512), (700, 700), (301, 419), (1024, 600)]:
+        pl = [{"object_id": 1, "box": [0, 0, dw, dh]}]
+        for filt in (nat.LANCZOS, nat.BILINEAR):
+            got, st = _composite(lib, ctx, nat, atlas, (dw, dh), (0, 0, 0, 0), pl, filt)
+            want = oracle.composite(np.zeros((dh, dw, 4), np.uint8), objs, pl, filt)
+            assert np.array_equal(got, want), ((dw, dh), filt, st)
+            marched += st["marched_layers"]
+    assert lib.mic_atlas_destroy(atlas) == 0
+    assert marched >= 8, marched

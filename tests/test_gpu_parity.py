@@ -5,6 +5,7 @@ reference.  Bar: bit-exact (8-bit integer arithmetic), which is inside north_sta
 Nothing here reads /root/reference; inputs are regenerated from seeds or come from
 tests/golden/bundles (data files).
 """
+import ctypes
 import json
 import os
 
@@ -457,6 +458,48 @@ def test_properties_full_size_lanczos_batches(gpu):
     torch.cuda.synchronize()
     for k in range(len(rows)):
         assert torch.equal(a[k], together[k]) and torch.equal(b[k], together[k]), k
+
+
+def test_alpha_over_every_triple_on_the_device(gpu):
+    """Exhaustive on the hardware: one 4096 x 4096 layer over a 4096 x 4096 background image whose pixel i carries
+    source alpha i & 255, source red (i >> 8) & 255 and destination red i >> 16 -- all 2^24 (alpha, source, destination)
+    triples of AlphaComposite.c's arithmetic go through the composite kernel's packed opaque-destination form
+    (kernels_composite.hip over_opaque_dst; the other channels ride along with permuted values) -- and, with a
+    translucent destination, through the verbatim formula.  Checked against the oracle."""
+    import torch
+    from image_transformation_amd.compositor import Atlas, composite_device, coerce_placements
+    n = 4096
+    i = np.arange(n * n, dtype=np.uint32).reshape(n, n)
+    sa, sc, dc = (i & 255).astype(np.uint8), ((i >> 8) & 255).astype(np.uint8), (i >> 16).astype(np.uint8)
+    src = np.stack([sc, sc ^ 0x5A, 255 - sc, sa], axis=2)
+    atlas = Atlas({1: src})
+    rows = coerce_placements(atlas, [{"object_id": 1, "box": [0, 0, n, n]}])
+    for dst_alpha in (255, None):
+        da = np.full_like(dc, 255) if dst_alpha == 255 else ((dc.astype(np.uint16) * 7 + sa * 3 + 1) & 255).astype(np.uint8)
+        bg = np.ascontiguousarray(np.stack([dc, dc ^ 0xA5, 255 - dc, da], axis=2))
+        got = composite_device(atlas, [torch.from_numpy(bg).cuda()], [rows])[0].cpu().numpy()
+        want = oracle.composite(bg, {1: src}, [{"object_id": 1, "box": [0, 0, n, n]}])
+        assert np.array_equal(got, want), dst_alpha
+
+
+def test_resize_every_colour_alpha_pair(gpu):
+    """Every (colour, alpha) pair through premultiply -> the MFMA digit-chain passes -> unpremultiply of the tile
+    kernel (mic_resize: single images take it; tests/test_gpu_march.py has the same through the marching kernel):
+    pixel (x, y) of a 256 x 256 quadrant is colour x at alpha y, mirrored 2 x 2, resized to shapes on both sides of 1."""
+    import torch
+    from image_transformation_amd import _native
+    x = np.arange(256, dtype=np.uint8)
+    c, a = np.meshgrid(x, x)
+    quad = np.stack([c, 255 - c, (c.astype(np.uint16) * 7 & 255).astype(np.uint8), a], axis=2)
+    top = np.concatenate([quad, quad[:, ::-1]], axis=1)
+    src = np.ascontiguousarray(np.concatenate([top, top[::-1]], axis=0))  # 512 x 512
+    dev = torch.from_numpy(src).cuda()
+    lib, P = _native.lib(), ctypes.c_void_p
+    for dw, dh in [(512, 513), (513, 512), (700, 700), (301, 419), (1024, 600), (90, 77)]:
+        for filt in (0, 1):
+            dst = torch.empty((dh, dw, 4), dtype=torch.uint8, device="cuda")
+            _native.check(lib.mic_resize(gpu.handle, P(dev.data_ptr()), 512, 512, P(dst.data_ptr()), dw, dh, filt, P(gpu.stream_ptr())))
+            assert np.array_equal(dst.cpu().numpy(), oracle.resize(src, (dw, dh), filt)), (dw, dh, filt)
 
 
 def test_ragged_and_extreme_shapes(gpu):
