@@ -103,6 +103,13 @@ def cpu_baseline(objs, placements, size, budget_s=12.0, max_reps=5000):
                       f"{med * 1e3:.1f} ms, oracle/mic_oracle.c single thread"}
 
 
+class _Sized:
+    """What the Flex placer needs of a cutout: .size = (w, h)."""
+
+    def __init__(self, a):
+        self.size = (a.shape[1], a.shape[0])
+
+
 def _pillow_composite(bg, imgs, placements):
     """This file's own restatement of the reference's loop (compositor.py:6-22); the reference's files
     are not on the GPU box."""
@@ -337,6 +344,19 @@ def timed_steps(D: Dist, ctx, plan, out_sets, steps, warmup):
     return elapsed, elapsed_min, kernel_ms, n_br
 
 
+def c4_partition(n_var: int, world: int, sizes):
+    """Who renders what in the strong-scaling leg: variant v -> rank v mod G (batch.shard_indices).  Pure: the CPU
+    tests check the G = 8 split the driver's node will run (64 canvases, 8 per rank, ONE canvas class per rank: the
+    ratios cycle with period 4, so ranks 3 and 7 hold every 4399-wide canvas and decide the step time)."""
+    from image_transformation_amd.batch import shard_indices
+
+    out = []
+    for r in range(world):
+        mine = shard_indices(n_var, r, world)
+        out.append({"rank": r, "variants": mine, "canvas_sizes": sorted({tuple(sizes[v]) for v in mine})})
+    return out
+
+
 def c4_strong_leg(D: Dist, args, steps, warmup):
     """BASELINE.json configs[3] exactly: ONE 32-object bundle, a FIXED batch of 64 aspect-ratio variants (4 ratios x
     16 Flex JSONs: canvases 2160x3840 / 2880x2880 / 3840x2160 / 4399x1885), variant v -> rank v mod G, one launch of
@@ -361,7 +381,9 @@ def c4_strong_leg(D: Dist, args, steps, warmup):
     torch.cuda.synchronize()
     bcast_warm_ms = (time.perf_counter() - t0) * 1e3
     ctx = atlas.ctx
-    mine = shard_indices(n_var, D.rank, D.world)
+    part = c4_partition(n_var, D.world, [v[0] for v in variants])
+    mine = part[D.rank]["variants"]
+    assert mine == shard_indices(n_var, D.rank, D.world)
     rows = [coerce_placements(atlas, flex.layout_to_placements(variants[v][1], atlas, variants[v][0])) for v in mine]
     plan = CompositeBatch(atlas, [SolidCanvas(variants[v][0], synthetic.SOLID_BG) for v in mine], rows)
     st = plan.stats()
@@ -407,6 +429,7 @@ def main():
                          "c4: strong scaling, BASELINE configs[3]'s fixed 64 variants split v mod G")
     ap.add_argument("--alpha", default="binary", choices=["binary", "soft", "opaque"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work the cpu_baseline sample may take")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements")
     args = ap.parse_args()
 
@@ -469,10 +492,16 @@ def main():
                          **leg["roofline_rank0"]},
             "per_rank": leg["per_rank"], "atlas": leg["atlas_broadcast"], "cpu_baseline": None, **ranks_info,
         }
+        if dist_on:
+            D.barrier()
+            dist.destroy_process_group()  # every collective is done: what follows is rank 0's own CPU time
+        if rank == 0 and not args.no_cpu_baseline:
+            c4objs, c4vars = synthetic.c4_workload(args.alpha, seed=4, n_variants=4)
+            sz, lay = c4vars[2]  # the 16:9 class: 3840 x 2160, the canvas the metric names
+            result["cpu_baseline"] = cpu_baseline(c4objs, flex.layout_to_placements(lay, {k: _Sized(v) for k, v in c4objs.items()}, sz),
+                                                  sz, budget_s=args.cpu_budget)
         if rank == 0:
             print(json.dumps(result), flush=True)
-        if dist_on:
-            dist.destroy_process_group()
         return
 
     B = args.batch
@@ -586,7 +615,9 @@ def main():
     # N = 1, 2, 4, 8 runs carry both curves: `value` (weak, B canvases per GPU) and `c4_strong.value` (64 fixed)
     if not args.no_extras or world > 1:
         del out_sets[1:]  # (memory: the C4 leg allocates 2 x 64/G canvases of its own)
-        c4, c4_atlas = c4_strong_leg(D, args, max(5, min(args.steps, 50)), max(2, min(args.warmup, 10)))
+        # (an extra, not the contract line: it does not inherit --steps.  At the driver's --steps 20 the G = 8 leg would be
+        # 20 x ~60 us = 1.2 ms of timed region, where one 50 us barrier skew is 4 %: >= 200 steps / >= 20 warm-up always)
+        c4, c4_atlas = c4_strong_leg(D, args, max(200, args.steps), max(20, args.warmup))
         result["c4_strong"] = c4
         del c4_atlas
         while len(out_sets) < n_sets:
@@ -595,17 +626,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_extras:
         extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_sets, n_sets, size, dev)
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(objs, placements[0], size)
-        result["cpu_baseline_all_cores"] = cpu_baseline_threads(objs, placements, size)
-        result["cpu_pillow"] = cpu_pillow(objs, placements[0], size)
+    if dist_on:
+        D.barrier()
+        dist.destroy_process_group()  # every collective is done: the CPU legs below are rank 0's own time
+    if rank == 0 and not args.no_cpu_baseline:
+        # at every N, so that a SCALE record is self-contained (the other ranks have left; nothing waits for this)
+        result["cpu_baseline"] = cpu_baseline(objs, placements[0], size, budget_s=args.cpu_budget)
+        if world == 1:
+            result["cpu_baseline_all_cores"] = cpu_baseline_threads(objs, placements, size)
+            result["cpu_pillow"] = cpu_pillow(objs, placements[0], size)
     elif rank == 0:
         result["cpu_baseline"] = None
 
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if dist_on:
-        dist.destroy_process_group()
 
 
 def _numpy_median_colour(img):
@@ -809,18 +843,42 @@ def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_
     # every byte of `roofline` crosses the HBM pins
     t0 = time.perf_counter()
     cold_sets = []
+
+    def variant(k):  # atlas k of a set: the same cutout sizes, other colours (alpha untouched) -- a canvas that read
+        # another canvas' atlas cannot pass the check below
+        if k == 0:
+            return objs
+        out = {}
+        for oid, a in objs.items():
+            b = a.copy()
+            b[:, :, :3] ^= np.uint8(k)
+            out[oid] = b
+        return out
     for s in range(2):
-        atl = [Atlas(objs) for _ in range(B)]
+        atl = [Atlas(variant(k)) for k in range(B)]
         cold_sets.append(CompositeBatch(atl, [solid] * B, rows, atlas_of=list(range(B))))
     torch.cuda.synchronize()
     for k in range(4):
         cold_sets[k % 2].run(out_sets[k % n_sets])
+    # parity before timing: the first and the last canvas of a multi-atlas launch against the CPU oracle, each with
+    # its own atlas' pixels (the checker, never the thing timed)
+    import oracle
+    verified = True
+    for s in range(2):
+        got = cold_sets[s].run(out_sets[s % n_sets])
+        torch.cuda.synchronize()
+        for k in (0, B - 1):
+            bg = np.empty((H, W, 4), np.uint8)
+            bg[:] = np.asarray(synthetic.SOLID_BG, np.uint8)
+            verified = verified and bool(np.array_equal(got[k].cpu().numpy(), oracle.composite(bg, variant(k), placements[k])))
+    assert verified, "cold_inputs: a multi-atlas launch differs from the oracle"
     c_ms, _ = bracketed(ctx, lambda k: cold_sets[k % 2].run(out_sets[k % n_sets], check=False), 30)
     st = cold_sets[0].stats()
     b = plan_bytes(st)
     result["cold_inputs"] = {
         "what": f"{B} canvases per launch, each reading an atlas of its own ({B} x {atlas.nbytes >> 20} MB), two such sets "
                 "and the output sets alternating: inputs 2 x 256 MB + outputs > 1 GB never re-used within 256 MB of traffic",
+        "verified": verified,  # canvases 0 and B-1 of both sets == the oracle on their own atlas' pixels, checked above
         "kernel_ms": round(c_ms, 4), "Mpixels_per_s": round(st["canvas_pixels"] / (c_ms * 1e-3) / 1e6, 1),
         "roofline": {"bound": "hbm", "achieved": round(b / (c_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": frac(b, c_ms), "algorithmic_bytes_per_launch": b,

@@ -739,13 +739,23 @@ def _stream_of(ctx: _native.Context) -> int:
 
 
 class _PendingDownload:
-    __slots__ = ("ctx", "ticket", "pin", "size")
+    __slots__ = ("ctx", "ticket", "pin", "size", "waited")
 
     def __init__(self, ctx, ticket, pin, size):
-        self.ctx, self.ticket, self.pin, self.size = ctx, ticket, pin, size
+        self.ctx, self.ticket, self.pin, self.size, self.waited = ctx, ticket, pin, size, False
+
+    def __del__(self):
+        # dropped without image() (an exception between enqueue and wait): the writer of `pin` must have finished
+        # before the block returns to the allocator
+        if not self.waited:
+            try:
+                _native.lib().mic_download_wait(self.ctx.handle, self.ticket)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
 
     def image(self) -> Image.Image:
         _native.check(_native.lib().mic_download_wait(self.ctx.handle, self.ticket))
+        self.waited = True
         w, h = self.size
         if _RESULT_COPY:
             im = Image.new("RGBA", (w, h), None)
@@ -867,9 +877,16 @@ def _composite_pil_background(atlas: Atlas, background_img: Image.Image, rows, f
         first = background_img.getpixel((0, 0))
         if background_img.getpixel((W - 1, H - 1)) == first and background_img.getpixel((W // 2, H // 2)) == first:
             pending = _composite_one(atlas, SolidCanvas((W, H), first), rows, filter)
-            if _rows_solid(table, W, H, first):
+            solid = False
+            try:
+                solid = _rows_solid(table, W, H, first)
+            finally:
+                # whatever happens in the scan: the kernel (or copy) that writes into pending's pinned block has
+                # finished before the block can go back to torch's host allocator (it knows nothing of that kernel)
+                if not solid:
+                    _native.lib().mic_download_wait(pending.ctx.handle, pending.ticket)
+            if solid:
                 return pending.image()
-            _native.check(_native.lib().mic_download_wait(pending.ctx.handle, pending.ticket))  # (discarded)
     return _composite_one(atlas, _upload(background_img, atlas.ctx), rows, filter).image()
 
 

@@ -220,18 +220,6 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
     const Job *__restrict__ jobs, const Layer *__restrict__ layers, const Job one, const LayerPack pack) {
     const Job job = MODE != kFromTables ? one : jobs[blockIdx.y];
     if ((int)blockIdx.x >= job.n_pages) return;
-#ifdef MIC_EXP_SALU  // experiment: this many extra scalar instructions per page (is the kernel scalar-issue sensitive?)
-#pragma unroll
-    for (int i_ = 0; i_ < MIC_EXP_SALU; ++i_) asm volatile("s_add_u32 s101, s101, 1" ::: "s101");
-#endif
-#ifdef MIC_EXP_VALU  // ... or extra vector instructions
-    {
-        int t_ = threadIdx.x;
-#pragma unroll
-        for (int i_ = 0; i_ < MIC_EXP_VALU; ++i_) asm volatile("v_add_u32 %0, %0, 1" : "+v"(t_));
-        if (t_ == 0x7fffffff) return;
-    }
-#endif
     const int lane = threadIdx.x;
     const int W = job.W;
     const int64_t n_px = (int64_t)job.W * job.H;

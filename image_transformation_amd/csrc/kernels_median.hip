@@ -192,7 +192,20 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBat
     __shared__ uint32_t res[3][2];
     __shared__ uint32_t is_last;
     const MedianImage &I = B.img[blockIdx.y];
-    if (blockIdx.x >= I.blocks) return;  // (block-uniform; such a block takes no ticket)
+    // The other half of the scratch double buffer -- what the previous call on this context used (stream order: it has
+    // finished) -- is cleared by EVERY block of the grid, the ones without pixels of their own included, 16 bytes per
+    // store: after a 16-image batch (0.8 MB) a small single-image call would otherwise zero all of it from one block,
+    // in front of its first barrier.  Plain stores; the kernel boundary publishes them to the next call.
+    auto clear_previous_half = [&]() {
+        if (!B.zero_words) return;
+        const uint32_t n_thr = gridDim.x * gridDim.y * blockDim.x, n16 = B.zero_words >> 2;  // (slots are multiples of 16 bytes)
+        u32x4 *z = reinterpret_cast<u32x4 *>(B.zero_ptr);
+        for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += n_thr) z[i] = u32x4{0u, 0u, 0u, 0u};
+    };
+    if (blockIdx.x >= I.blocks) {  // (block-uniform; such a block takes no ticket)
+        clear_previous_half();
+        return;
+    }
     const uint32_t *__restrict__ px = I.px;
     const size_t n_px = I.n_px;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -211,11 +224,7 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBat
     }
     for (int i = threadIdx.x; i < 2 * kSetWords * kCopies; i += blockDim.x) lh[i] = 0;
     if (threadIdx.x < 2) lcount[threadIdx.x] = 0;
-    // the other half of the scratch double buffer: what the previous call on this context used (stream order: it has
-    // finished).  Plain stores in the shadow of the loads above; the kernel boundary publishes them to the next call.
-    if (blockIdx.y == 0 && B.zero_words) {
-        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < B.zero_words; i += I.blocks * blockDim.x) B.zero_ptr[i] = 0u;
-    }
+    clear_previous_half();  // in the shadow of the loads above
     __syncthreads();
 
     if (packed) {

@@ -332,19 +332,7 @@ __device__ __forceinline__ const MIC_GLOBAL T *at(uint64_t base, uint32_t byte_o
 // Every tile of both axes of a layer that comes here has its taps inside ONE 64-sample window (any scale down to
 // ~1/3: the host checks it per layer; deeper shrinks, single images and small calls take the tile kernel of
 // kernels_resample_tile.hip) -- no chunk loops, their registers or their branches.
-#ifdef MIC_RS_PROBE  // tuning builds only (scripts/build_variant.sh probe -DMIC_RS_PROBE; scripts/rs_timeline.py reads it):
-// per workgroup, the start / end of its first wave on the 100 MHz clock and where that wave's cycles went
-__device__ unsigned long long g_rs_probe[16384 * 12];
-extern "C" int mic_debug_rs_probe(unsigned long long *out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rs_probe), sizeof(unsigned long long) * 12 * (size_t)n) != hipSuccess;
-}
-#define MIC_PROBE(...) __VA_ARGS__
-#else
-#define MIC_PROBE(...)
-#endif
 __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const RsMarch *__restrict__ jobs) {
-    MIC_PROBE(const unsigned long long p_t0 = __builtin_amdgcn_s_memrealtime(); const unsigned long long p_c0 = __builtin_amdgcn_s_memtime();
-              unsigned long long p_b1 = 0; unsigned long long p_ld = 0; unsigned long long p_h = 0; unsigned long long p_v = 0; unsigned long long p_loop = 0;)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
     __shared__ float recip[256];            // unpremultiply factors 255/a: an LDS read per pixel
     __shared__ v4i vm_lds[kRsMaxSegTiles];  // the unit's vertical tile table
@@ -435,11 +423,8 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
     }
     uint32_t zmask = 0;   // bit s: ring slot s holds an all-zero band
     const uint32_t ring_bits = (uint32_t)((1ull << J.ring16) - 1ull);
-    MIC_PROBE(p_loop = __builtin_amdgcn_s_memtime();)
     for (int b = band0; b <= band_last; ++b) {
-        MIC_PROBE(const unsigned long long q0 = __builtin_amdgcn_s_memtime();)
         __syncthreads();  // every wave is done reading the previous band
-        MIC_PROBE(const unsigned long long q1 = __builtin_amdgcn_s_memtime(); p_b1 += q1 - q0;)
         {
 #pragma unroll
             for (int k = 0; k < 2; ++k)
@@ -466,7 +451,6 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
             }
         }
         __syncthreads();  // the band (and its alpha flag) is in LDS
-        MIC_PROBE(const unsigned long long q2 = __builtin_amdgcn_s_memtime(); p_ld += q2 - q1;)
         if (b < band_last) prefetch(b + 1);
         const bool zero_band = __builtin_amdgcn_readfirstlane((int)band_alpha) == 0;
         const int slot = b & rmask;
@@ -487,7 +471,6 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
                 for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m + 16 * c) = w[c];
             }
         }
-        MIC_PROBE(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long q3 = __builtin_amdgcn_s_memtime(); p_h += q3 - q2;)
         // ---- tiles of output rows whose last tap row is now in the ring (the next tile's table entry waits in
         // scalar registers: a band that completes no tile costs one compare)
         while (yt < n_yt && v_hi <= 16 * (b + 1)) {
@@ -532,17 +515,7 @@ __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const
             ++yt;
             v_ws = n_ws; v_hi = n_hi;
         }
-        MIC_PROBE(p_v += __builtin_amdgcn_s_memtime() - q3;)
     }
-    MIC_PROBE(if (tid == 0) {
-        const unsigned wg = blockIdx.y * 32u + blockIdx.x;
-        if (wg < 16384u) {
-            g_rs_probe[12 * wg + 0] = p_t0; g_rs_probe[12 * wg + 1] = __builtin_amdgcn_s_memrealtime();
-            g_rs_probe[12 * wg + 3] = (unsigned long long)(band_last - band0 + 1) | ((unsigned long long)n_yt << 32);
-            g_rs_probe[12 * wg + 4] = p_loop - p_c0; g_rs_probe[12 * wg + 5] = p_b1; g_rs_probe[12 * wg + 6] = p_ld;
-            g_rs_probe[12 * wg + 7] = p_h; g_rs_probe[12 * wg + 8] = p_v; g_rs_probe[12 * wg + 9] = __builtin_amdgcn_s_memtime() - p_c0;
-        }
-    })
 }
 
 hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, size_t lds_bytes, hipStream_t stream) {

@@ -184,6 +184,7 @@ struct mic_ctx {
     static constexpr int kDownloads = 16;
     hipEvent_t dl_event[kDownloads] = {};
     bool dl_pending[kDownloads] = {};
+    uint32_t dl_gen[kDownloads] = {};  // how often the entry has been handed out: a ticket is (generation << 8) | entry
     int dl_next = 0;
     mic_stats stats{};
     uint64_t next_atlas_uid = 1;
@@ -1688,22 +1689,27 @@ extern "C" int mic_download(mic_ctx *ctx, const void *src_dev, void *dst_host, s
     if (bytes > 0) HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipEventRecord(ctx->dl_event[t], stream));
     ctx->dl_pending[t] = true;
-    *ticket = t;
+    ctx->dl_gen[t] = (ctx->dl_gen[t] + 1) & 0x7fffffu;
+    *ticket = (int32_t)((ctx->dl_gen[t] << 8) | (uint32_t)t);
     return MIC_OK;
 }
 
 extern "C" int mic_download_wait(mic_ctx *ctx, int32_t ticket) {
-    if (!ctx || ticket < 0 || ticket >= mic_ctx::kDownloads) return fail(MIC_ERR_INVALID, "mic_download_wait: bad arguments");
+    const int slot = ticket & 0xff;
+    const uint32_t gen = (uint32_t)ticket >> 8;
+    if (!ctx || ticket < 0 || slot >= mic_ctx::kDownloads) return fail(MIC_ERR_INVALID, "mic_download_wait: bad arguments");
     hipEvent_t ev;
     {
         std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-        if (!ctx->dl_pending[ticket]) return MIC_OK;
-        ev = ctx->dl_event[ticket];
+        // A ticket of an earlier generation: the entry has come round again, and mic_download waited for the old record
+        // before it re-recorded the event -- that copy has landed, and the entry now belongs to someone else.
+        if (ctx->dl_gen[slot] != gen || !ctx->dl_pending[slot]) return MIC_OK;
+        ev = ctx->dl_event[slot];
     }
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipEventSynchronize(ev));  // (not under the lock: other threads keep enqueueing)
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-    ctx->dl_pending[ticket] = false;
+    if (ctx->dl_gen[slot] == gen) ctx->dl_pending[slot] = false;  // (a newer holder's flag is not this call's to clear)
     return MIC_OK;
 }
 

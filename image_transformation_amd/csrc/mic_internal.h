@@ -185,6 +185,7 @@ hipError_t launch_rect_outlines(void *out, int W, int H, const OutlineRect *rect
 // of its first loads, what the previous call left in the other.
 constexpr int kMedianMaxBatch = 16;
 constexpr size_t kMedianSlotWords = 8 * (2 * 3 * 256 + 16) + 8;
+static_assert(kMedianSlotWords % 4 == 0, "the median kernel clears the scratch 16 bytes at a time");
 constexpr size_t kMedianScratchWords = 2 * kMedianMaxBatch * kMedianSlotWords;
 struct MedianView {
     const void *px;     // device RGBA

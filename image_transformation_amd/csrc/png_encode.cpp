@@ -260,7 +260,11 @@ struct Buf {
             // rounded up generously: the stripes of one image differ by a row, the images of one run by little --
             // a pooled buffer should fit the next request (a fresh one is an mmap plus page faults, which serialise
             // the workers on the process's address-space lock)
+#ifdef MIC_PNG_EXACT_ALLOC  // sanitizer builds: no slack, so that a bound that is too small is an ASan report
+            const size_t want = n;
+#else
             const size_t want = (n + n / 8 + ((size_t)256 << 10)) & ~(((size_t)64 << 10) - 1);
+#endif
             mem.reset();
             mem.reset(new uint8_t[want + 64]);
             cap = want;
@@ -302,9 +306,13 @@ struct BitWriter {
     }
 };
 
-// Most bytes deflate_stripe can produce for n input bytes: every block is at most its stored form (the cheapest of
-// the three encodings is emitted, priced exactly), blocks cover >= 64 Ki input bytes except the last one.
-inline size_t deflate_bound(size_t n) { return n + (n / 65535 + 4) * 8 + 64; }
+// Most bytes deflate_stripe can produce for n input bytes.  Every block is at most its stored form (the cheapest of
+// the three encodings is emitted, priced exactly) plus one byte of bit alignment behind a Huffman block; the stored
+// form of a block of r bytes is r + 5 * ceil(r / 65535).  A block closes after kBlockTokens = 65535 tokens or
+// kBlockRaw input bytes, so every block but a stripe's last covers >= 65535 bytes: at most n / 65535 + 1 blocks, and
+// over all of them sum(5 * ceil(r / 65535) + 1) <= 5 * (n / 65535 + blocks) + blocks <= 11 * (n / 65535 + 1) + 6.
+// (+ 64: the zlib header, the closing empty stored block, the bit writer's 4-byte stores.)
+inline size_t deflate_bound(size_t n) { return n + 12 * (n / 65535 + 2) + 64; }
 
 // ---------------------------------------------------------------------------------------- block emission
 // token: literal = byte value (< 256); match = 0x80000000 | (len - 3) << 16 | (dist - 1)
@@ -477,7 +485,9 @@ void emit_block(BitWriter &bw, const uint32_t *tok, size_t n, const uint32_t *ll
 
 // ---------------------------------------------------------------------------------------- LZ77 of one stripe
 constexpr int kHashBits = 15;
-constexpr size_t kBlockTokens = 1 << 16;
+// (65535, not 65536: a block of incompressible data is that many literals, and its stored form is then ONE stored
+// sub-block of 65535 bytes instead of 65535 + 1)
+constexpr size_t kBlockTokens = 65535;
 constexpr size_t kBlockRaw = 1 << 18;  // a block also ends after this many input bytes (stored fallback granularity)
 
 inline uint32_t load32(const uint8_t *p) {
@@ -724,6 +734,7 @@ void encode_stripe(const uint8_t *const *rows, int32_t w, Stripe *s, bool first,
         c[n++] = 0x01;
     }
     n += deflate_stripe(filt, raw, level, last, c + n, sc);
+    if (n > deflate_bound(raw) + 24) abort();  // the unchecked bit writer ran past what deflate_bound promised: a bug, not an input
     sc->out_len = finish_chunk(c, n);
 }
 
@@ -743,8 +754,11 @@ int plan_threads(int32_t w, int32_t h, int threads) {
 size_t png_bound(int32_t w, int32_t h) {
     if (w <= 0 || h <= 0) return 0;
     const uint64_t raw = (uint64_t)h * ((uint64_t)w * 4 + 1);
-    // stored blocks: 5 bytes per 65535, + per stripe chunk framing / sync blocks, + signature, IHDR, trailer, IEND
-    return (size_t)(raw + raw / 65535 * 5 + 64 * 40 + 1024);
+    // the stripes' deflate_bound()s (12 bytes per 65535 in all, + 88 per stripe) + 12 bytes of chunk framing per
+    // stripe; at most raw / 256 KiB + 1 stripes whatever `threads` says (png_encode_rows); + signature, IHDR, the
+    // Adler trailer chunk, IEND
+    const uint64_t stripes = std::min<uint64_t>((uint64_t)h, raw / ((uint64_t)256 << 10) + 1);
+    return (size_t)(raw + raw / 65535 * 12 + stripes * 128 + 1024);
 }
 
 PngPieces::~PngPieces() {

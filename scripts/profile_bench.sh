@@ -1,11 +1,12 @@
 #!/bin/bash
+cd "${GRAFT_REPO_ROOT:?run through gpurun: GRAFT_REPO_ROOT names the copy of the repo on the GPU box}" || exit 1
 # rocprofv3 evidence for bench.py's roofline line: kernel-trace stats, then HBM byte counters in
 # separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950).
 # Usage (on the GPU box, from the repo root): scripts/profile_bench.sh <tag>
 tag=${1:-r01}
 out=gpurun_out/prof_$tag
 mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp  # (already in the repo copy: line 2)
 args="bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 $args > $out/kt.log 2>&1
 cp $out/kt/*/*kernel_stats.csv $out/kernel_stats.csv

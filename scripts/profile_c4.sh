@@ -1,6 +1,7 @@
 #!/bin/bash
+cd "${GRAFT_REPO_ROOT:?run through gpurun: GRAFT_REPO_ROOT names the copy of the repo on the GPU box}" || exit 1
 # Kernel-only roofline fraction of the composite kernel per C4 aspect ratio (rocprofv3 kernel trace).
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp  # (already in the repo copy: line 2)
 for r in 0 1 2 3; do
   rm -rf gpurun_out/pc4
   MIC_RATIO=$r rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/pc4 -- python3 scripts/prof_c4.py > gpurun_out/pc4.log 2>&1 || { tail -5 gpurun_out/pc4.log; exit 1; }

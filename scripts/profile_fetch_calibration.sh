@@ -1,7 +1,8 @@
 #!/bin/bash
+cd "${GRAFT_REPO_ROOT:?run through gpurun: GRAFT_REPO_ROOT names the copy of the repo on the GPU box}" || exit 1
 # FETCH_SIZE / TCC_EA0_RDREQ calibration per access shape (scripts/calib_fetch.hip) and the same counters on the
 # resample launch (scripts/prof_placements.py): which correction applies to the band loader's 64-byte row segments.
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp  # (already in the repo copy: line 2)
 out=gpurun_out/prof_fetch_calib
 rm -rf $out && mkdir -p $out
 for c in FETCH_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "TCC_READ_sum" WRITE_SIZE; do

@@ -1,6 +1,7 @@
 #!/bin/bash
+cd "${GRAFT_REPO_ROOT:?run through gpurun: GRAFT_REPO_ROOT names the copy of the repo on the GPU box}" || exit 1
 # Kernel-trace durations of the median kernel per case (tuning knobs: MIC_MEDIAN_DBG, MIC_MEDIAN_BLOCKS).
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp  # (already in the repo copy: line 2)
 mkdir -p gpurun_out
 for c in 3840x2160:noise 3840x2160:flat 7680x4320:noise 7680x4320:sprinkle 492x492:sprinkle; do
   export MIC_CASE=$c

@@ -1,7 +1,8 @@
 #!/bin/bash
+cd "${GRAFT_REPO_ROOT:?run through gpurun: GRAFT_REPO_ROOT names the copy of the repo on the GPU box}" || exit 1
 # rocprofv3 view of the marching resample kernel on the C3 placements workload (32 LANCZOS layers per canvas).
 # usage: scripts/profile_resample.sh [outdir]   (MIC_ALPHA=soft|binary)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp  # (already in the repo copy: line 2)
 out=${1:-gpurun_out/prof_rs}
 rm -rf $out && mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- python3 scripts/prof_placements.py > $out/kt.log 2>&1 || { tail -5 $out/kt.log; exit 1; }

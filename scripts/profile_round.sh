@@ -1,11 +1,12 @@
 #!/bin/bash
+cd "${GRAFT_REPO_ROOT:?run through gpurun: GRAFT_REPO_ROOT names the copy of the repo on the GPU box}" || exit 1
 # rocprofv3 evidence of a round: kernel traces and HBM byte counters (FETCH_SIZE and WRITE_SIZE in separate --pmc
 # passes: they do not fit one pass on gfx950) for (1) bench.py's headline batch, (2) its cold-inputs leg, (3) the
 # placements-mode canvas (resample + composite), (4) single-canvas launches.  Usage: scripts/profile_round.sh r02
 tag=${1:-r02}
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp  # (already in the repo copy: line 2)
 run() {  # run <name> <python args...>: kernel trace + FETCH + WRITE passes
   name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name/kt -- python3 "$@" > $out/$name.kt.log 2>&1 || { echo "FAILED kt $name"; tail -5 $out/$name.kt.log; return 1; }

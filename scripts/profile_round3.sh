@@ -1,11 +1,12 @@
 #!/bin/bash
+cd "${GRAFT_REPO_ROOT:?run through gpurun: GRAFT_REPO_ROOT names the copy of the repo on the GPU box}" || exit 1
 # rocprofv3 evidence of round 3 -> gpurun_out/prof_r03 (copied into profiles/r03_* afterwards): kernel traces + HBM byte
 # counters (FETCH_SIZE, WRITE_SIZE in separate --pmc passes) for bench.py's headline batch, the C4 strong-scaling leg,
 # the placements canvas (resample + composite), single-canvas launches, C5 at 8K and the contact sheet.
 tag=r03
 out=gpurun_out/prof_$tag
 rm -rf $out && mkdir -p $out
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp  # (already in the repo copy: line 2)
 kt() {  # kt <name> <python args...>: kernel trace + stats
   name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/$name/kt -- python3 "$@" > $out/$name.kt.log 2>&1 || { echo "FAILED kt $name"; tail -5 $out/$name.kt.log; return 1; }

@@ -1,4 +1,4 @@
-"""Timeline of the marching resample kernel's workgroups (tuning build: scripts/build_variant.sh probe -DMIC_RS_PROBE,
+"""Timeline of the marching resample kernel's workgroups (tuning build: git apply profiles/r04_tuning_scaffolding.patch, then scripts/build_variant.sh probe -DMIC_RS_PROBE,
 run with MIC_LIB=scripts/var_probe.bin): per workgroup the start / end (100 MHz clock) of its first wave -> resident
 workgroups over time, duration spread, tail, and what list scheduling of those durations could reach."""
 import ctypes, heapq, os, sys

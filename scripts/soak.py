@@ -10,14 +10,14 @@ import oracle
 from image_transformation_amd import _native, synthetic
 from PIL import Image
 from image_transformation_amd.background_resizing import median_colors_device
-from image_transformation_amd.compositor import Atlas, SolidCanvas, composite, composite_device, coerce_placements
+from image_transformation_amd.compositor import Atlas, CompositeBatch, SolidCanvas, composite, composite_device, coerce_placements
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
 rng = np.random.default_rng(seed)
 ctx = _native.context(); lib = _native.lib(); P = ctypes.c_void_p
 t_end = time.time() + budget
-n_comp = n_rs = n_pil = n_med = 0
+n_comp = n_rs = n_pil = n_med = n_multi = 0
 t_say = time.time() + 30
 while time.time() < t_end:
     if time.time() > t_say:  # progress line: long silent GPU runs are taken for hung
@@ -64,6 +64,34 @@ while time.time() < t_end:
                                              sizes={k: v.shape for k, v in objs.items()}))
             sys.exit(1)
         n_comp += 1
+    # ---- round 4: ONE plan over several atlases (CompositeBatch(atlas_of=...), mic_plan_create with n_atlases > 1): the
+    # same ids name other cutouts in the second atlas; every canvas against the oracle on its own atlas' objects
+    objs2 = {k: synthetic.make_cutout(rng, int(rng.integers(1, 200)), int(rng.integers(1, 160)), ["binary", "soft"][int(rng.integers(0, 2))]) for k in objs}
+    atlas2 = Atlas(objs2)
+    both, n_cv = [objs, objs2], int(rng.integers(2, 7))
+    a_of = [int(rng.integers(0, 2)) for _ in range(n_cv)]
+    cvs, bgs, pls = [], [], []
+    for i in range(n_cv):
+        W, H = int(rng.choice([3, 64, 257, 1000, 1025, 2049])), int(rng.integers(1, 60))
+        pl = []
+        for _k in range(int(rng.integers(0, 12))):
+            oid = int(rng.integers(1, len(objs) + 2))
+            sh, sw = both[a_of[i]].get(oid, both[a_of[i]][1]).shape[:2]
+            if rng.random() < 0.4:
+                sw, sh = max(1, int(sw * rng.uniform(0.3, 2.2))), max(1, int(sh * rng.uniform(0.3, 2.2)))
+            x1, y1 = int(rng.integers(-sw - 1, W + 1)), int(rng.integers(-sh - 1, H + 1))
+            pl.append({"object_id": oid, "box": [x1, y1, x1 + sw, y1 + sh]})
+        col = tuple(int(v) for v in rng.integers(0, 256, 4)) if rng.random() < 0.5 else (38, 73, 115, 255)
+        bg_np = np.empty((H, W, 4), np.uint8); bg_np[:] = col
+        cvs.append(SolidCanvas((W, H), col)); bgs.append(bg_np); pls.append(pl)
+    filt = int(rng.integers(0, 2))
+    mplan = CompositeBatch([atlas, atlas2], cvs, [coerce_placements(both[a_of[i]], pls[i]) for i in range(n_cv)], filter=filt, atlas_of=a_of)
+    for i, o in enumerate(mplan.run()):
+        if not np.array_equal(o.cpu().numpy(), oracle.composite(bgs[i], both[a_of[i]], pls[i], filt)):
+            print("MULTI-ATLAS MISMATCH", dict(seed=seed, canvas=i, atlas_of=a_of, filt=filt, pl=pls[i]))
+            sys.exit(1)
+        n_multi += 1
+    del mplan, atlas2
     # ---- round 3: the PIL-level drop-in (speculative solid background, layer records in the kernel arguments, small
     # canvases written straight into pinned host memory, event-waited downloads) and the batched strided median
     pil_objs = {k: Image.fromarray(v, "RGBA") for k, v in objs.items()}
@@ -125,4 +153,4 @@ while time.time() < t_end:
         print("PLAN RESIZE MISMATCH", dict(seed=seed, src=(sw, sh), dst=(dw, dh), filt=filt))
         sys.exit(1)
     n_rs += 1
-print(f"soak ok: {n_comp} composites, {n_pil} PIL drop-in composites, {n_med} batched medians, {n_rs} resizes, seed {seed}, {budget:.0f} s, MIC_RS_MARCH_MIN_UNITS={os.environ.get('MIC_RS_MARCH_MIN_UNITS')}")
+print(f"soak ok: {n_comp} composites, {n_multi} multi-atlas canvases, {n_pil} PIL drop-in composites, {n_med} batched medians, {n_rs} resizes, seed {seed}, {budget:.0f} s, MIC_RS_MARCH_MIN_UNITS={os.environ.get('MIC_RS_MARCH_MIN_UNITS')}")

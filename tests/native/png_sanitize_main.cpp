@@ -56,6 +56,29 @@ int main(int argc, char **argv) {
                 }
         }
     }
+    // big incompressible images on ONE thread (a single stripe of 67 MB: ~1000 deflate blocks that all fall
+    // back to stored) -- the total must stay inside png_bound and the stripe inside deflate_bound; the second pass
+    // reuses the pooled scratch of the first (this binary is built with -DMIC_PNG_EXACT_ALLOC: buffers hold exactly
+    // what was asked for, so a bound that is too small is an ASan report, not silent slack)
+    {
+        const int w = 4096, h = 4096;
+        std::vector<uint8_t> img((size_t)w * h * 4);
+        for (auto &b : img) b = (uint8_t)rnd();
+        std::vector<const uint8_t *> rows((size_t)h);
+        for (int y = 0; y < h; ++y) rows[(size_t)y] = img.data() + (size_t)y * w * 4;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int level = 1; level >= 0; --level) {
+                mic::PngPieces out;
+                std::string err;
+                if (mic::png_encode_rows(rows.data(), w, h, level, 1, &out, &err) != 0) { printf("encode failed: %s\n", err.c_str()); return 1; }
+                if (out.total() > mic::png_bound(w, h)) {
+                    printf("bound exceeded 4096x4096 noise level %d: %zu > %zu\n", level, out.total(), mic::png_bound(w, h));
+                    return 1;
+                }
+                if (pass == 0) for (const auto &p : out.pieces) mix(p.data, p.size);
+                ++n_ok;
+            }
+    }
     // the asynchronous writer: a burst of jobs on the library's worker threads, files into argv[1]
     if (argc > 1) {
         const int w = 300, h = 200;

@@ -67,6 +67,55 @@ def test_world_size_2_gloo(tmp_path):
     assert sorted(os.listdir(tmp_path)) == ["ok0", "ok1"]
 
 
+def _worker8(rank, world, port, tmpdir):
+    """One of 8 CPU ranks: bench.py's own N > 1 protocol objects (Dist: barrier, max / min, sum, gather) and the C4
+    partition, over gloo -- no GPU is touched (the pool allows at most six processes on a card, so the 8-rank case
+    cannot be rehearsed on the one-GPU box)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+
+    import bench
+    from image_transformation_amd import synthetic
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        D = bench.Dist(world, rank, torch.device("cpu"), rehearsal=True)
+        assert D.active and D.backend == "gloo"
+        _, variants = synthetic.c4_workload("binary", seed=4, n_variants=64) if rank == 0 else (None, None)
+        sizes = [None]
+        if rank == 0:
+            sizes = [[list(v[0]) for v in variants]]
+        dist.broadcast_object_list(sizes, src=0)  # (only rank 0 pays for generating the cutouts)
+        part = bench.c4_partition(64, world, [tuple(x) for x in sizes[0]])
+        mine = part[rank]
+        assert len(mine["variants"]) == 8 and all(v % world == rank for v in mine["variants"])
+        classes = [(2160, 3840), (2880, 2880), (3840, 2160), (4399, 1885)]
+        assert mine["canvas_sizes"] == [classes[rank % 4]]  # ONE class per rank at G = 8
+        D.barrier()
+        # timing protocol: value = units of ALL ranks / MAX over ranks of the timed region
+        px = float(sum(sizes[0][v][0] * sizes[0][v][1] for v in mine["variants"]))
+        total = D.sum(px)
+        assert total == float(sum(w * h for w, h in sizes[0]))
+        mx, mn = D.max_min(0.001 * (rank + 1))
+        assert abs(mx - 0.008) < 1e-12 and abs(mn - 0.001) < 1e-12
+        got = D.gather({"rank": rank, "n": len(mine["variants"])})
+        assert [g["rank"] for g in got] == list(range(world)) and sum(g["n"] for g in got) == 64
+        with open(os.path.join(tmpdir, f"ok{rank}"), "w") as f:
+            f.write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_c4_partition_and_protocol_8_ranks(tmp_path):
+    import torch.multiprocessing as mp
+
+    world, port = 8, _free_port()
+    mp.spawn(_worker8, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == [f"ok{r}" for r in range(8)]
+
+
 def test_shard_indices_edges():
     from image_transformation_amd.batch import shard_indices
     assert shard_indices(0, 0, 4) == []

@@ -112,7 +112,7 @@ def test_png_encoder_under_asan_ubsan(tmp_path):
         pytest.skip("g++ not available")
     out = str(tmp_path / "png_sanitize")
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
-           "-fno-omit-frame-pointer", "-I", CSRC, os.path.join(ROOT, "tests", "native", "png_sanitize_main.cpp"),
+           "-fno-omit-frame-pointer", "-DMIC_PNG_EXACT_ALLOC", "-I", CSRC, os.path.join(ROOT, "tests", "native", "png_sanitize_main.cpp"),
            os.path.join(CSRC, "png_encode.cpp"), "-lpthread", "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0 and "asan" in (r.stderr or "").lower() and "cannot find" in r.stderr.lower():
