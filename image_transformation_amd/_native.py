@@ -14,7 +14,7 @@ from typing import Dict, Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MIC_LIB") or os.path.join(_HERE, "libmic.so")  # MIC_LIB: an alternative build (tuning runs)
 
-ABI_VERSION = (1, 8)  # mic_version(): include/mic.h as this file binds it
+ABI_VERSION = (1, 9)  # mic_version(): include/mic.h as this file binds it
 LANCZOS = 0
 BILINEAR = 1
 ERR_FORMAT = -5
@@ -53,7 +53,7 @@ class ImageView(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in
                 ("canvas_pixels", "layer_pixels", "source_pixels", "resampled_layers", "identity_layers",
-                 "skipped_placements", "composite_blocks", "marched_layers")]
+                 "skipped_placements", "composite_blocks", "marched_layers", "cached_layers", "pipeline_groups")]
 
     def as_dict(self) -> Dict[str, int]:
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -88,6 +88,8 @@ SYMBOLS = {
                                        ctypes.c_int, ctypes.POINTER(_P)]),
     "mic_plan_run": (ctypes.c_int, [_P, ctypes.POINTER(_P), _P]),
     "mic_plan_destroy": (ctypes.c_int, [_P]),
+    "mic_plan_invalidate": (ctypes.c_int, [_P]),
+    "mic_layer_cache_clear": (ctypes.c_int, [_P]),
     "mic_plan_stats": (ctypes.c_int, [_P, ctypes.POINTER(Stats)]),
     "mic_resize": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.c_int32, _P, ctypes.c_int32, ctypes.c_int32,
                                   ctypes.c_int, _P]),

@@ -281,8 +281,10 @@ class Atlas(Mapping):
     needs (macro_placement_test.py:645,708 only read img.size).
     """
 
-    def __init__(self, objects: Mapping[int, Any], device: Optional[int] = None):
-        self.ctx = _native.context(device)
+    def __init__(self, objects: Mapping[int, Any], device: Optional[int] = None, ctx: Optional[_native.Context] = None):
+        """ctx: a context other than the process-wide one of the device (tests and tuning scripts make their own,
+        with other MIC_* settings read by mic_create)."""
+        self.ctx = ctx if ctx is not None else _native.context(device)
         host = pack_blob(objects, pin=True)  # packed straight into pinned memory: one host copy, then the DMA
         torch = _torch()
         blob = torch.empty(host.numel(), dtype=torch.uint8, device=self.ctx.torch_device)
@@ -656,6 +658,10 @@ class CompositeBatch:
         st = _native.Stats()
         _native.check(_native.lib().mic_plan_stats(self.handle, ctypes.byref(st)))
         return st.as_dict()
+
+    def invalidate(self) -> None:
+        """The next run() resamples the plan's layers again (they are otherwise kept from the first run on)."""
+        _native.check(_native.lib().mic_plan_invalidate(self.handle))
 
     def run(self, outs: Optional[Sequence[Any]] = None, check: bool = True):
         """Enqueue the batch on torch's current stream (not synchronised); returns the outputs.

@@ -219,13 +219,16 @@ template <bool ALIGNED, bool SOLID, int MODE>
 __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6 : 4)) void composite_kernel(
     const Job *__restrict__ jobs, const Layer *__restrict__ layers, const Job one, const LayerPack pack) {
     const Job job = MODE != kFromTables ? one : jobs[blockIdx.y];
-    if ((int)blockIdx.x >= job.n_pages) return;
+    // (page_begin: a band launch of the pipelined LANCZOS path covers pages [page_begin, n_pages) of its canvas; a
+    // multiple of 8, so the page <-> XCD pairing holds)
+    const int page = (int)blockIdx.x + (MODE != kFromTables ? job.page_begin : 0);
+    if (page >= job.n_pages) return;
     const int lane = threadIdx.x;
     const int W = job.W;
     const int64_t n_px = (int64_t)job.W * job.H;
     const Layer *jl = MODE == kAllInArgs ? pack.l : layers + job.layer_begin;
 
-    const int64_t qp = (int64_t)blockIdx.x * kPagePx - job.px_shift;
+    const int64_t qp = (int64_t)page * kPagePx - job.px_shift;
     // pages that lie wholly inside the canvas: all but the first/last of a page-misaligned canvas
     if (qp < 0 || W < kLaneNPx) {
         edge_page(job, jl, qp, lane);

@@ -52,7 +52,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *mic_last_error(void) { return g_err; }
-extern "C" int mic_version(void) { return (1 << 16) | 8; }  // 1.8: + mic_png_write_async / mic_png_wait; 1.7: + mic_median_rgb_batch, mic_host_rows_solid, mic_download(_wait); 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
+extern "C" int mic_version(void) { return (1 << 16) | 9; }  // 1.9: + mic_plan_invalidate, mic_layer_cache_clear, mic_stats.cached_layers / pipeline_groups (resident resampled layers, pipelined LANCZOS path); 1.8: + mic_png_write_async / mic_png_wait; 1.7: + mic_median_rgb_batch, mic_host_rows_solid, mic_download(_wait); 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
 
 // ------------------------------------------------------------------------------------ blob layout
 namespace {
@@ -188,6 +188,46 @@ struct mic_ctx {
     int dl_next = 0;
     mic_stats stats{};
     uint64_t next_atlas_uid = 1;
+    // ---- the LANCZOS path as ONE path (round 4).  The resample kernel is bound by instruction issue and leaves wave
+    // slots idle over its ramp and tail, the composite kernel is bound by memory: they overlap well.  A call's resampled
+    // layers are cut into GROUPS in the order the composite needs them -- by canvas in multi-canvas calls, by canvas BAND
+    // (a run of 4 KiB pages) in single-canvas calls -- the groups' resample launches go to side streams, and the
+    // composite of a chunk of canvases / a band is enqueued on the caller's stream behind the event of the last group it
+    // reads: it runs while the next group is being resampled.  Outputs are complete once the caller's stream has drained
+    // (its last composite waits for the last group), as before.
+    static constexpr int kSideStreams = 3;
+    hipStream_t side[kSideStreams] = {};
+    std::vector<hipEvent_t> pipe_events;  // pool (timing disabled), reused call after call
+    // MEASURED (profiles/r04_pipeline_streams.txt): on this runtime a cross-stream dependency (event record on one HIP
+    // stream + hipStreamWaitEvent on another) costs 15-50 us of GPU idle time per edge -- more than the composite it would
+    // hide (C3 placements canvas: 73 us serial, 98-430 us with 2-12 bands; 16 canvases per call: 58.7 us per canvas
+    // serial, 63-107 us in chunks) -- whatever the event flags.  So both knobs default to the serial path; the groups
+    // below are what the FUSED launches (kernels_fused.hip) are cut by instead.
+    int pipe_bands = 1;    // MIC_PIPE_BANDS: bands of a single-canvas call (<= 1: resample, then composite, on one stream)
+    int pipe_chunk = 0;    // MIC_PIPE_CHUNK: canvases per chunk of a multi-canvas call (<= 0: serial)
+    int pipe_streams = 1;  // MIC_PIPE_STREAMS: side streams the groups are dealt over (1: the groups run one after another)
+    bool pipe_prio = false;  // MIC_PIPE_PRIO=1: side streams created with descending priorities
+    unsigned pipe_evflags = hipEventDisableTiming;  // MIC_PIPE_EVFLAGS (hex): flags of the group events
+    // ---- resampled layers stay resident (round 4): a transient call (mic_composite_batch, mic_render, mic_contact_sheet)
+    // writes its resampled layers into this cache instead of the arena, keyed (atlas, cutout, box size, filter); a later
+    // call that places the same cutout at the same size -- a refine iteration that moves a box without resizing it
+    // (macro_placement_test.py:1679-1697), the contact sheet's thumbnails -- finds the pixels and skips the resample.
+    // Bump-allocated regions, everything dropped at once when full (entries are re-made on demand); MIC_LAYER_CACHE_MB
+    // (default 2048, 0 = off).  Persistent plans keep their resampled layers in their own scratch (mic_plan: resident).
+    struct LayerKey {
+        uint64_t atlas_uid;
+        int32_t entry, w, h, filter;
+        bool operator<(const LayerKey &o) const {
+            return std::tie(atlas_uid, entry, w, h, filter) < std::tie(o.atlas_uid, o.entry, o.w, o.h, o.filter);
+        }
+    };
+    struct LayerRegion {
+        char *dev = nullptr;
+        size_t cap = 0, used = 0;
+    };
+    std::map<LayerKey, uint64_t> layer_cache;  // -> device address of the resampled pixels
+    std::vector<LayerRegion> layer_regions;
+    size_t layer_cache_cap = (size_t)2048 << 20, layer_cache_total = 0;
     // optional event brackets around the kernels (mic_profile_begin/end)
     std::vector<hipEvent_t> prof_events;  // 3 per call: before resample, before composite, after
     int prof_calls = 0, prof_max = 0, prof_every = 1, prof_seen = 0;
@@ -250,6 +290,12 @@ extern "C" int mic_create(int device, mic_ctx **out) {
         }
     }
     if (const char *la = getenv("MIC_LAYER_ARGS")) ctx->layer_args = atoi(la) != 0;
+    if (const char *v = getenv("MIC_PIPE_BANDS")) ctx->pipe_bands = std::max(1, std::min(64, atoi(v)));
+    if (const char *v = getenv("MIC_PIPE_CHUNK")) ctx->pipe_chunk = std::max(0, atoi(v));
+    if (const char *v = getenv("MIC_PIPE_STREAMS")) ctx->pipe_streams = std::max(1, std::min((int)mic_ctx::kSideStreams, atoi(v)));
+    if (const char *v = getenv("MIC_PIPE_PRIO")) ctx->pipe_prio = atoi(v) != 0;
+    if (const char *v = getenv("MIC_PIPE_EVFLAGS")) ctx->pipe_evflags = (unsigned)strtoul(v, nullptr, 16);
+    if (const char *v = getenv("MIC_LAYER_CACHE_MB")) ctx->layer_cache_cap = (size_t)std::max(0ll, atoll(v)) << 20;
     if (const char *tl = getenv("MIC_MEDIAN_TWO_LAUNCHES")) ctx->median_two_launches = atoi(tl) != 0 ? 1 : 0;
     e = hipMalloc(&ctx->median_scratch, (kMedianScratchWords + 64) * sizeof(uint32_t));
     // zeroed once: every median call clears the half of the double buffer the call before it used
@@ -280,6 +326,11 @@ extern "C" int mic_destroy(mic_ctx *ctx) {
     for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->dl_event)
         if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : ctx->pipe_events) (void)hipEventDestroy(ev);
+    for (hipStream_t st : ctx->side)
+        if (st) (void)hipStreamDestroy(st);
+    for (auto &r : ctx->layer_regions)
+        if (r.dev) (void)hipFree(r.dev);
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->median_scratch) (void)hipFree(ctx->median_scratch);
     if (ctx->gradient_table) (void)hipFree(ctx->gradient_table);
@@ -629,6 +680,10 @@ struct ResizePlan {
     uint64_t planar_src = 0;  // the cutout in its atlas' planar premultiplied copy (0: none)
     int planar_pitch = 0;
     int atlas = -1, entry = -1;  // where the source is a cutout of an atlas
+    // where the composite first needs the layer: the first job that places it, and the top-most canvas row of its
+    // boxes in that job (the pipelined path resamples in that order)
+    int first_job = 0, first_row = 0;
+    bool cached = false;  // the pixels are in the context's resident layer cache already (dst_ptr): no pass is emitted
 };
 
 struct PassTables {
@@ -641,6 +696,11 @@ struct PassTables {
     size_t lds_march = 0;
     std::vector<RsJob> h, v;
     int max_h_out_w = 0, max_h_rows = 0, max_v_out_w = 0, max_v_out_h = 0;
+    // The marching entries are emitted in the order the composite needs their layers: by first job, then by first
+    // canvas row.  marks[k] = that key of the k-th marching layer and the number of entries up to and including it,
+    // so "everything jobs <= j / rows <= y need" is a prefix of `fused`.
+    struct Mark { int job, row, fused_end; };
+    std::vector<Mark> marks;
 };
 
 // Over all groups of `per` consecutive 16-sample tiles along one axis: the largest window extent a
@@ -759,7 +819,16 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
     for (const ResizePlan &p : plans)
         if (p.march) march_px += (int64_t)p.dw * p.dh;
     const int64_t unit_px = march_unit_px(march_px);
-    for (const ResizePlan &p : plans) {
+    std::vector<size_t> order;  // marching layers first, in need order; then the others in plan order
+    for (size_t i = 0; i < plans.size(); ++i)
+        if (plans[i].march && !plans[i].cached) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+        return std::make_pair(plans[a].first_job, plans[a].first_row) < std::make_pair(plans[b].first_job, plans[b].first_row);
+    });
+    for (size_t i = 0; i < plans.size(); ++i)
+        if (!plans[i].march && !plans[i].cached) order.push_back(i);
+    for (const size_t pi : order) {
+        const ResizePlan &p = plans[pi];
         const bool need_h = p.dw != p.sw, need_v = p.dh != p.sh;
         const uint64_t dst = p.dst_ptr ? p.dst_ptr : arena + p.dst_off;
         if (p.march) {
@@ -783,6 +852,7 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             f.xcd_rot = pt->fused_layers++ & 7;  // the XCD that gets a layer's short last run rotates
             for (f.entry = 0; f.entry < f.n_entries; ++f.entry) pt->fused.push_back(f);
             pt->lds_march = std::max(pt->lds_march, rs_march_lds_bytes(f.pitch_c, f.pitch_r));
+            pt->marks.push_back({p.first_job, p.first_row, (int)pt->fused.size()});
             continue;
         }
         if (p.tx16 > 0) {
@@ -882,10 +952,17 @@ struct mic_plan {
         int class_end[3] = {0, 0, 0};
         int pitch = 0;
         uint64_t last_use = 0;
+        std::vector<int> order_idx;  // position in the (class-sorted) device table -> caller's job index
     };
     static constexpr int kJobTables = 4;
     JobTable job_tables[kJobTables];
     uint64_t run_counter = 0;
+    // Persistent plans: the resampled layers of the plan's placements live in its own scratch and are a pure function
+    // of the (immutable) atlases, so a later run finds them there and only composites -- a refine iteration, a batch
+    // re-rendered onto other canvases.  mic_plan_invalidate() makes the next run resample again (bench.py's cold legs).
+    bool resampled_valid = false;
+    std::vector<int> order_idx;  // ordered[k] is the caller's job order_idx[k] (this run)
+    int pipeline_groups = 1;     // resample groups of the last run (stats)
 };
 
 static void plan_offsets(mic_plan *P) {
@@ -895,6 +972,94 @@ static void plan_offsets(mic_plan *P) {
     P->off_h = align_up(P->off_t + sizeof(RsTile) * P->pt.tiles.size(), 64);
     P->off_v = align_up(P->off_h + sizeof(RsJob) * P->pt.h.size(), 64);
     P->total = align_up(P->off_v + sizeof(RsJob) * P->pt.v.size(), 64);
+}
+
+// ---- resident layer cache (see mic_ctx) -----------------------------------------------------------------------------
+static size_t layer_bytes(const ResizePlan &rp) { return align_up((size_t)rp.dw * rp.dh * 4 + kGuard, kPixelAlign); }
+
+static void layer_cache_drop(mic_ctx *ctx) {  // forget every entry (the regions stay allocated and are refilled)
+    ctx->layer_cache.clear();
+    for (auto &r : ctx->layer_regions) r.used = kPixelAlign;  // (leading guard band)
+}
+
+static uint64_t layer_cache_alloc(mic_ctx *ctx, size_t bytes) {
+    for (auto &r : ctx->layer_regions)
+        if (r.used + bytes <= r.cap) {
+            const uint64_t at = reinterpret_cast<uint64_t>(r.dev) + r.used;
+            r.used += bytes;
+            return at;
+        }
+    // a new region: big enough for this layer, 128 MiB otherwise, inside the cap
+    size_t want = std::max(bytes + kPixelAlign, (size_t)128 << 20);
+    if (ctx->layer_cache_total + want > ctx->layer_cache_cap) want = ctx->layer_cache_cap - std::min(ctx->layer_cache_cap, ctx->layer_cache_total);
+    if (want < bytes + kPixelAlign) return 0;
+    mic_ctx::LayerRegion r;
+    if (hipMalloc(reinterpret_cast<void **>(&r.dev), want) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    r.cap = want;
+    r.used = kPixelAlign + bytes;
+    ctx->layer_cache_total += want;
+    ctx->layer_regions.push_back(r);
+    return reinterpret_cast<uint64_t>(r.dev) + kPixelAlign;
+}
+
+// Give every resampled layer of a transient call its place in the resident cache: a hit (same cutout, same box size,
+// same filter, placed by an earlier call) needs no pass at all; a miss is resampled into the cache instead of the arena.
+// false: the cache is off or cannot hold this call's layers at once -- the call uses the arena as before.
+static bool layer_cache_assign(mic_ctx *ctx, mic_atlas *const *atlases, std::vector<ResizePlan> &plans, int filter,
+                               uint64_t *hits) {
+    if (ctx->layer_cache_cap == 0 || plans.empty()) return false;
+    size_t total = kPixelAlign;
+    for (const ResizePlan &rp : plans) total += layer_bytes(rp);
+    if (total > ctx->layer_cache_cap) return false;
+    auto key_of = [&](const ResizePlan &rp) {
+        return mic_ctx::LayerKey{atlases[rp.atlas]->uid, rp.entry, rp.dw, rp.dh, filter};
+    };
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool ok = true;
+        *hits = 0;
+        std::vector<std::pair<mic_ctx::LayerKey, uint64_t>> fresh;
+        for (ResizePlan &rp : plans) {
+            const auto key = key_of(rp);
+            auto it = ctx->layer_cache.find(key);
+            if (it != ctx->layer_cache.end()) {
+                rp.dst_ptr = it->second;
+                rp.cached = true;
+                ++*hits;
+                continue;
+            }
+            rp.cached = false;
+            rp.dst_ptr = layer_cache_alloc(ctx, layer_bytes(rp));
+            if (!rp.dst_ptr) {
+                ok = false;
+                break;
+            }
+            fresh.push_back({key, rp.dst_ptr});
+        }
+        if (ok) {
+            for (const auto &kv : fresh) ctx->layer_cache[kv.first] = kv.second;
+            return true;
+        }
+        // no room beside what is cached: drop everything and place the whole call again (its layers fit an empty
+        // cache unless the regions are fragmented -- then the regions go too, and ONE region of the right size comes)
+        layer_cache_drop(ctx);
+        if (attempt == 0) {
+            bool fits = false;
+            for (const auto &r : ctx->layer_regions) fits |= r.cap >= total;
+            if (!fits && ctx->layer_cache_total + total > ctx->layer_cache_cap) {
+                if (hipStreamSynchronize(ctx->last_stream) != hipSuccess) break;
+                for (auto &r : ctx->layer_regions) (void)hipFree(r.dev);
+                ctx->layer_regions.clear();
+                ctx->layer_cache_total = 0;
+            }
+        }
+        for (ResizePlan &rp : plans) { rp.dst_ptr = 0; rp.cached = false; }
+    }
+    for (ResizePlan &rp : plans) { rp.dst_ptr = 0; rp.cached = false; }
+    layer_cache_drop(ctx);
+    return false;
 }
 
 static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs, const mic_job *jobs,
@@ -974,19 +1139,17 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                 size_t plan_idx;
                 if (dit != dedup.end()) {
                     plan_idx = dit->second;
+                    if (plans[plan_idx].first_job == ji)
+                        plans[plan_idx].first_row = std::min(plans[plan_idx].first_row, (int)std::max<int64_t>(0, y1));
                 } else {
                     ResizePlan rp{};
                     rp.src = reinterpret_cast<uint64_t>(A->blob) + E.offset;
                     rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
                     rp.atlas = Pl.atlas; rp.entry = it->second;
+                    rp.first_job = ji;
+                    rp.first_row = (int)std::max<int64_t>(0, y1);
                     if (int rc = choose_march(ctx, &rp, filter)) return rc;
                     if (int rc = choose_tile(ctx, &rp, filter)) return rc;
-                    if (rp.tx16 == 0 && rp.dw != rp.sw && rp.dh != rp.sh) {  // the two-pass fallback's intermediate
-                        rp.tmp_off = scratch_need;
-                        scratch_need = align_up(scratch_need + (size_t)rp.dw * rp.sh * 4 + kGuard, kPixelAlign);
-                    }
-                    rp.dst_off = scratch_need;
-                    scratch_need = align_up(scratch_need + (size_t)rp.dw * rp.dh * 4 + kGuard, kPixelAlign);
                     plan_idx = plans.size();
                     plans.push_back(rp);
                     dedup.emplace(key, plan_idx);
@@ -998,12 +1161,29 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
         d.layer_count = (int32_t)P->layers.size() - d.layer_begin;
         P->jobs[(size_t)ji] = d;
     }
+    // transient calls: resampled layers go to (or are found in) the context's resident cache
+    if (!persistent) {
+        uint64_t hits = 0;
+        if (layer_cache_assign(ctx, atlases, plans, filter, &hits)) st.cached_layers = hits;
+    }
+    // scratch: the two-pass fallback's intermediates, and every layer that has no place of its own
+    for (ResizePlan &rp : plans) {
+        if (rp.cached) continue;
+        if (rp.tx16 == 0 && rp.dw != rp.sw && rp.dh != rp.sh) {
+            rp.tmp_off = scratch_need;
+            scratch_need = align_up(scratch_need + (size_t)rp.dw * rp.sh * 4 + kGuard, kPixelAlign);
+        }
+        if (!rp.dst_ptr) {
+            rp.dst_off = scratch_need;
+            scratch_need = align_up(scratch_need + (size_t)rp.dw * rp.dh * 4 + kGuard, kPixelAlign);
+        }
+    }
     P->stats = st;
 
     if (scratch_need > ((size_t)64 << 30))
         return fail(MIC_ERR_NOMEM, "resampled layers of this call need %zu bytes of scratch", scratch_need);
     void *scratch = nullptr;
-    if (plans.empty()) {
+    if (plans.empty() || scratch_need <= kPixelAlign) {  // nothing to resample, or every layer has its place in the cache
         scratch_need = 0;
     } else if (persistent) {
         HIP_TRY(hipMalloc(&P->scratch, scratch_need));
@@ -1014,7 +1194,8 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
         scratch = ctx->arena;
     }
     for (const Pending &pd : pending)
-        P->layers[pd.layer].src = reinterpret_cast<uint64_t>(scratch) + plans[pd.plan].dst_off;
+        P->layers[pd.layer].src = plans[pd.plan].dst_ptr ? plans[pd.plan].dst_ptr
+                                                          : reinterpret_cast<uint64_t>(scratch) + plans[pd.plan].dst_off;
     // Route the layers that qualify for the marching kernel: it wins once the call has enough work units to fill
     // the chip (its units are long chains of dependent bands; a few of them are a serial tail) and pays for the
     // cutouts' planar copies, which a persistent plan or a bundle's later calls amortise.  Everything else goes to
@@ -1022,15 +1203,15 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
     {
         int64_t px = 0;
         for (const ResizePlan &rp : plans)
-            if (rp.march_ok) px += (int64_t)rp.dw * rp.dh;
+            if (rp.march_ok && !rp.cached) px += (int64_t)rp.dw * rp.dh;
         const int64_t unit_px = march_unit_px(px);
         int64_t units = 0;
         for (const ResizePlan &rp : plans)
-            if (rp.march_ok) units += march_units(rp, unit_px, nullptr);
+            if (rp.march_ok && !rp.cached) units += march_units(rp, unit_px, nullptr);
         const bool use_march = units >= ctx->march_min_units;
         for (size_t i = 0; i < plans.size(); ++i) {
             ResizePlan &rp = plans[i];
-            rp.march = rp.march_ok && use_march;
+            rp.march = rp.march_ok && use_march && !rp.cached;
             if (rp.march) ++P->stats.marched_layers;
             if (rp.march) planar_need[(size_t)rp.atlas].push_back({rp.entry, i});
         }
@@ -1166,8 +1347,16 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
             key.resize((size_t)n_jobs);
             for (int ji = 0; ji < n_jobs; ++ji) key[(size_t)ji] = P->ordered[(size_t)ji].out;
         }
-        std::stable_sort(P->ordered.begin(), P->ordered.end(),
-                         [&](const Job &a, const Job &b) { return job_class(a) < job_class(b); });
+        {
+            std::vector<int> idx((size_t)n_jobs);
+            for (int ji = 0; ji < n_jobs; ++ji) idx[(size_t)ji] = ji;
+            const std::vector<Job> &src = P->ordered;
+            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return job_class(src[(size_t)a]) < job_class(src[(size_t)b]); });
+            std::vector<Job> sorted((size_t)n_jobs);
+            for (int k = 0; k < n_jobs; ++k) sorted[(size_t)k] = src[(size_t)idx[(size_t)k]];
+            P->ordered.swap(sorted);
+            P->order_idx.swap(idx);
+        }
         for (const Job &d : P->ordered)
             for (int c = job_class(d); c < 3; ++c) ++class_end[c];
 
@@ -1207,8 +1396,10 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
             slot_tab->outs = std::move(key);
             memcpy(slot_tab->class_end, class_end, sizeof class_end);
             slot_tab->pitch = pitch;
+            slot_tab->order_idx = P->order_idx;
         }
     }
+    const std::vector<int> &order_idx = cached ? slot_tab->order_idx : P->order_idx;
     const Job *jobs_dev = one ? nullptr : (P->persistent ? slot_tab->dev : reinterpret_cast<const Job *>(dp));
 
     for (const auto &todo : P->planar_todo) {
@@ -1220,21 +1411,129 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     const bool prof = ctx->profiling && ctx->prof_calls < ctx->prof_max && (ctx->prof_seen++ % ctx->prof_every) == 0;
     hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], stream));
-    HIP_TRY(launch_resample_march(reinterpret_cast<const RsMarch *>(dp + P->off_f), (int)P->pt.fused.size(),
-                                   P->pt.lds_march, stream));
-    HIP_TRY(launch_resample_tile(reinterpret_cast<const RsTile *>(dp + P->off_t), (int)P->pt.tiles.size(),
-                                  P->pt.tiles_whole, P->pt.tiles_lds, stream));
-    HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + P->off_h), (int)P->pt.h.size(),
-                              P->pt.max_h_out_w, P->pt.max_h_rows, stream));
-    HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + P->off_v), (int)P->pt.v.size(),
-                              P->pt.max_v_out_w, P->pt.max_v_out_h, stream));
-    if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
-    HIP_TRY(launch_composite(jobs_dev, reinterpret_cast<const Layer *>(dp + P->off_layers), n_jobs, class_end, pitch,
-                             one ? &P->ordered[0] : nullptr, pack_layers ? P->layers.data() : nullptr, stream));
+    const Layer *layers_dev = reinterpret_cast<const Layer *>(dp + P->off_layers);
+    const RsMarch *fused_dev = reinterpret_cast<const RsMarch *>(dp + P->off_f);
+    // a persistent plan that has run before finds its resampled layers in its own scratch: composite only
+    const bool resident = P->persistent && P->resampled_valid;
+    P->pipeline_groups = 1;
+    if (!resident) {
+        HIP_TRY(launch_resample_tile(reinterpret_cast<const RsTile *>(dp + P->off_t), (int)P->pt.tiles.size(),
+                                      P->pt.tiles_whole, P->pt.tiles_lds, stream));
+        HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + P->off_h), (int)P->pt.h.size(),
+                                  P->pt.max_h_out_w, P->pt.max_h_rows, stream));
+        HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + P->off_v), (int)P->pt.v.size(),
+                                  P->pt.max_v_out_w, P->pt.max_v_out_h, stream));
+    }
+    // ---- groups of the pipelined path (see mic_ctx): {marching entries [fb, fe), the part of the composite that may
+    // follow them: sorted jobs [a, b), or pages [a, b) of the only job}
+    struct Group { int fb, fe, a, b; };
+    std::vector<Group> groups;
+    const int n_fused = resident ? 0 : (int)P->pt.fused.size();
+    const std::vector<PassTables::Mark> &marks = P->pt.marks;
+    if (n_fused > 0 && marks.size() > 1) {
+        if (one && ctx->pipe_bands > 1) {
+            const Job &d = P->ordered[0];
+            const int64_t n_px = (int64_t)d.W * d.H;
+            const int bands = std::min(ctx->pipe_bands, std::max(1, d.n_pages / 64));  // >= 64 pages (256 KiB) per band
+            int done = 0;
+            for (int k = 0; k < bands; ++k) {
+                const int p0 = (int)((int64_t)d.n_pages * k / bands) / 8 * 8;
+                const int p1 = k + 1 == bands ? d.n_pages : (int)((int64_t)d.n_pages * (k + 1) / bands) / 8 * 8;
+                if (p1 <= p0) continue;
+                // the last canvas row the band's pages touch; every layer whose first row is <= that may be read
+                const int64_t q_last = std::min<int64_t>(n_px - 1, (int64_t)p1 * kPagePx - d.px_shift - 1);
+                const int row_last = (int)(q_last / d.W);
+                auto it = std::upper_bound(marks.begin(), marks.end(), row_last,
+                                           [](int row, const PassTables::Mark &m) { return row < m.row; });
+                const int fe = k + 1 == bands ? n_fused : std::max(done, it == marks.begin() ? 0 : (it - 1)->fused_end);
+                groups.push_back({done, fe, p0, p1});
+                done = fe;
+            }
+        } else if (!one && ctx->pipe_chunk > 0 && n_jobs > ctx->pipe_chunk) {
+            // chunks of pipe_chunk canvases in table order; the last chunk is cut in halves (.., 2, 1, 1) so that the
+            // composite nothing is left to hide is a small one
+            std::vector<int> cuts;
+            int at = 0;
+            while (n_jobs - at > ctx->pipe_chunk) { at += ctx->pipe_chunk; cuts.push_back(at); }
+            for (int rest = n_jobs - at; rest > 1; rest -= rest / 2) { at += rest / 2; cuts.push_back(at); }
+            cuts.push_back(n_jobs);
+            int a = 0, done = 0, need_job = -1;
+            for (int b : cuts) {
+                for (int k = a; k < b; ++k) need_job = std::max(need_job, order_idx[(size_t)k]);
+                auto it = std::upper_bound(marks.begin(), marks.end(), need_job,
+                                           [](int job, const PassTables::Mark &m) { return job < m.job; });
+                const int fe = b == n_jobs ? n_fused : std::max(done, it == marks.begin() ? 0 : (it - 1)->fused_end);
+                groups.push_back({done, fe, a, b});
+                done = fe;
+                a = b;
+            }
+        }
+        int with_work = 0;
+        for (const Group &g : groups) with_work += g.fe > g.fb;
+        if (with_work < 2) groups.clear();  // nothing to overlap: the serial path
+    }
+    if (groups.empty()) {
+        HIP_TRY(launch_resample_march(fused_dev, n_fused, P->pt.lds_march, stream));
+        if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
+        HIP_TRY(launch_composite(jobs_dev, layers_dev, n_jobs, class_end, pitch, one ? &P->ordered[0] : nullptr,
+                                 pack_layers ? P->layers.data() : nullptr, stream));
+    } else {
+        P->pipeline_groups = (int)groups.size();
+        const int n_side = std::min(ctx->pipe_streams, (int)mic_ctx::kSideStreams);
+        for (int k = 0; k < n_side; ++k)
+            if (!ctx->side[k]) {
+                int lo = 0, hi = 0;
+                if (ctx->pipe_prio) HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi: the numerically lowest = greatest priority)
+                HIP_TRY(hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, ctx->pipe_prio ? std::min(lo, hi + k) : 0));
+            }
+        // events: one that orders the side streams behind everything the caller's stream holds (table uploads, planar
+        // copies, the previous call's composites reading the same scratch), one per group
+        auto event_at = [&](size_t i, hipEvent_t *ev) -> int {
+            while (ctx->pipe_events.size() <= i) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreateWithFlags(&e, ctx->pipe_evflags));
+                ctx->pipe_events.push_back(e);
+            }
+            *ev = ctx->pipe_events[i];
+            return MIC_OK;
+        };
+        hipEvent_t ev_start;
+        if (int rc = event_at(0, &ev_start)) return rc;
+        HIP_TRY(hipEventRecord(ev_start, stream));
+        for (int k = 0; k < n_side; ++k) HIP_TRY(hipStreamWaitEvent(ctx->side[k], ev_start, 0));
+        std::vector<hipEvent_t> gev(groups.size(), nullptr);
+        int dealt = 0;
+        for (size_t g = 0; g < groups.size(); ++g) {
+            const Group &G = groups[g];
+            if (G.fe <= G.fb) continue;
+            hipStream_t st = ctx->side[dealt++ % n_side];
+            HIP_TRY(launch_resample_march(fused_dev + G.fb, G.fe - G.fb, P->pt.lds_march, st));
+            if (int rc = event_at(1 + g, &gev[g])) return rc;
+            HIP_TRY(hipEventRecord(gev[g], st));
+        }
+        for (size_t g = 0; g < groups.size(); ++g) {
+            const Group &G = groups[g];
+            if (gev[g]) HIP_TRY(hipStreamWaitEvent(stream, gev[g], 0));
+            if (prof && g + 1 == groups.size()) HIP_TRY(hipEventRecord(pe[1], stream));
+            if (one) {
+                Job band = P->ordered[0];
+                band.page_begin = G.a;
+                band.n_pages = G.b;
+                HIP_TRY(launch_composite(nullptr, layers_dev, 1, class_end, (G.b - G.a + 7) / 8 * 8, &band,
+                                         pack_layers ? P->layers.data() : nullptr, stream));
+            } else {
+                int ce[3];
+                for (int c = 0; c < 3; ++c) ce[c] = std::min(std::max(class_end[c], G.a), G.b) - G.a;
+                HIP_TRY(launch_composite(jobs_dev + G.a, layers_dev, G.b - G.a, ce, pitch, nullptr, nullptr, stream));
+            }
+        }
+    }
     if (prof) {
         HIP_TRY(hipEventRecord(pe[2], stream));
         ++ctx->prof_calls;
     }
+    if (P->persistent) P->resampled_valid = true;
+    P->stats.pipeline_groups = (uint64_t)P->pipeline_groups;
     P->stats.composite_blocks = (uint64_t)pitch * n_jobs;
     ctx->stats = P->stats;
     return MIC_OK;
@@ -1246,8 +1545,24 @@ extern "C" int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (int rc = adopt_stream(ctx, stream)) return rc;  // before the transient plan may regrow the arena
     mic_plan P;
-    if (int rc = plan_build(ctx, n_atlases, atlases, n_jobs, jobs, filter, /*persistent=*/false, stream, &P)) return rc;
-    return plan_submit(&P, nullptr, stream);
+    int rc = plan_build(ctx, n_atlases, atlases, n_jobs, jobs, filter, /*persistent=*/false, stream, &P);
+    if (rc == MIC_OK) rc = plan_submit(&P, nullptr, stream);
+    // a failed call may have entered layers into the resident cache whose resample never ran: forget them all
+    if (rc != MIC_OK && !ctx->layer_cache.empty()) layer_cache_drop(ctx);
+    return rc;
+}
+
+extern "C" int mic_layer_cache_clear(mic_ctx *ctx) {
+    CTX_ENTER(ctx);
+    layer_cache_drop(ctx);
+    return MIC_OK;
+}
+
+extern "C" int mic_plan_invalidate(mic_plan *plan) {
+    if (!plan) return fail(MIC_ERR_INVALID, "mic_plan_invalidate: null plan");
+    CTX_ENTER(plan->ctx);
+    plan->resampled_valid = false;
+    return MIC_OK;
 }
 
 extern "C" int mic_render(mic_ctx *ctx, mic_atlas *atlas, const char *layout_json, size_t len, int32_t width,

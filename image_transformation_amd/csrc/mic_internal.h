@@ -44,8 +44,8 @@ struct alignas(16) Job {
     int32_t W, H;
     int32_t layer_begin, layer_count;
     int32_t px_shift;  // pixels of the canvas' first 4 KiB page that precede the canvas: (out % 4096) / 4
-    int32_t n_pages;   // ceil((W*H + px_shift) / 1024)
-    int32_t pad0;
+    int32_t n_pages;   // ceil((W*H + px_shift) / 1024); a band launch: one past the band's last page
+    int32_t page_begin;  // first page this launch covers (a multiple of 8; 0 except in the band launches of the pipelined LANCZOS path)
 };
 static_assert(sizeof(Job) == 48, "Job layout");
 

@@ -144,6 +144,16 @@ int mic_plan_create(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int 
                     const mic_job *jobs, int filter, mic_plan **out);
 int mic_plan_run(mic_plan *plan, void *const *outs, void *stream);
 int mic_plan_destroy(mic_plan *plan);
+/* Resampled layers stay resident (1.9).  A cutout resized to a box's size (compositor.py:20) is a pure function of
+ * (cutout, box size, filter) and the atlas is immutable while it exists, so the pixels are kept where they were
+ * written: a persistent plan keeps them in its own scratch -- the first mic_plan_run resamples, later runs only
+ * composite (the refine loop moving boxes onto other canvases, macro_placement_test.py:1679-1697) -- and transient
+ * calls (mic_composite_batch, mic_render, mic_contact_sheet) keep theirs in a per-context cache keyed (atlas, object,
+ * box size, filter), MIC_LAYER_CACHE_MB (default 2048, 0 = off).  Results are bit-identical either way.
+ * mic_plan_invalidate: the plan's next run resamples again; mic_layer_cache_clear: the context forgets its cached
+ * layers (bench.py's cold legs call these; a caller that overwrites an atlas blob it owns in place must, too).       */
+int mic_plan_invalidate(mic_plan *plan);
+int mic_layer_cache_clear(mic_ctx *ctx);
 
 /* Image.resize((out_w,out_h), filter) of one device RGBA image (compositor.py:20 call shape;
  * also the thumbnail resample of macro_placement_test.py:194).                             */
@@ -287,6 +297,8 @@ typedef struct mic_stats {
     uint64_t skipped_placements;  /* unknown ids                                           */
     uint64_t composite_blocks;    /* workgroups launched by the composite kernel           */
     uint64_t marched_layers;      /* of resampled_layers: those run by the marching resample kernel (1.5) */
+    uint64_t cached_layers;       /* of the call's distinct resampled layers: found in the resident cache (1.9) */
+    uint64_t pipeline_groups;     /* resample groups the call's launches were cut into; 1 = resample, then composite (1.9) */
 } mic_stats;
 int mic_last_stats(const mic_ctx *ctx, mic_stats *out);
 int mic_plan_stats(const mic_plan *plan, mic_stats *out);
@@ -294,7 +306,11 @@ int mic_plan_stats(const mic_plan *plan, mic_stats *out);
 /* Kernel timing with HIP events recorded on the launch stream, for bench.py's roofline: between
  * mic_profile_begin and mic_profile_end every mic_composite_batch call brackets its composite
  * kernel (and, separately, its resample passes) with an event pair.  mic_profile_end waits for
- * the stream, then reports the number of bracketed calls and the summed durations in ms.       */
+ * the stream, then reports the number of bracketed calls and the summed durations in ms.
+ * A call that runs the pipelined LANCZOS path (mic_stats.pipeline_groups > 1: resample groups on side
+ * streams, the composite of a band / a chunk of canvases behind each) reports as resample_ms the span
+ * up to the start of its LAST composite launch (earlier composites ran inside it) and as composite_ms
+ * that last launch: the sum is the call's whole GPU time on the stream either way.                */
 int mic_profile_begin(mic_ctx *ctx, int max_calls);
 /* Same, bracketing only every `every`-th call (an event pair between two back-to-back kernels costs
  * a few microseconds of idle GPU; sampling keeps the timed loop representative).                 */

@@ -1,0 +1,188 @@
+"""Round 4: the LANCZOS path as one path.  (1) The pipelined submission -- a call's marching resample launches cut into
+groups on side streams, the composite of a canvas band / a chunk of canvases behind each group's event -- gives the
+oracle's pixels for every knob setting (bands, chunks, side streams, priorities), on canvases small enough for the
+oracle, with every qualifying layer forced through the marching kernel.  (2) Resident resampled layers: a persistent
+plan's later runs and a context's later transient calls find the layers and skip the resample -- same pixels, the
+counters say so -- and mic_plan_invalidate / mic_layer_cache_clear / a full cache bring the resample back."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import cases  # noqa: E402
+import oracle  # noqa: E402
+
+P = ctypes.c_void_p
+KNOBS = ("MIC_PIPE_BANDS", "MIC_PIPE_CHUNK", "MIC_PIPE_STREAMS", "MIC_PIPE_PRIO", "MIC_RS_MARCH_MIN_UNITS", "MIC_LAYER_CACHE_MB")
+
+
+def _ctx(monkeypatch, **env):
+    import torch
+    from image_transformation_amd import _native
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need an MI355X")
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    return _native.Context(torch.cuda.current_device())
+
+
+def _scene(rng, n_obj, W, H, n_layers, alpha="soft"):
+    objs = {i + 1: cases.synthetic.make_cutout(rng, int(rng.integers(40, 200)), int(rng.integers(30, 160)), alpha) for i in range(n_obj)}
+    pl = []
+    for _ in range(n_layers):
+        oid = int(rng.integers(1, n_obj + 1))
+        sh, sw = objs[oid].shape[:2]
+        s = rng.uniform(0.5, 1.8)
+        w, h = (max(1, int(sw * s)), max(1, int(sh * s))) if rng.random() < 0.85 else (sw, sh)
+        x1, y1 = int(rng.integers(-w // 3, W - w // 2)), int(rng.integers(-h // 3, H - h // 2))
+        pl.append({"object_id": oid, "box": [x1, y1, x1 + w, y1 + h]})
+    return objs, pl
+
+
+@pytest.mark.parametrize("knobs", [dict(MIC_PIPE_BANDS=1, MIC_PIPE_CHUNK=0), dict(MIC_PIPE_BANDS=3), dict(MIC_PIPE_BANDS=8, MIC_PIPE_STREAMS=3),
+                                   dict(MIC_PIPE_BANDS=4, MIC_PIPE_STREAMS=2, MIC_PIPE_PRIO=1), dict(MIC_PIPE_CHUNK=1, MIC_PIPE_STREAMS=2),
+                                   dict(MIC_PIPE_CHUNK=3, MIC_PIPE_STREAMS=3, MIC_PIPE_PRIO=1)])
+def test_pipelined_path_matches_the_oracle(knobs, monkeypatch):
+    import torch
+    from image_transformation_amd import _native
+    from image_transformation_amd.compositor import Atlas, CompositeBatch, SolidCanvas, coerce_placements
+    ctx = _ctx(monkeypatch, MIC_RS_MARCH_MIN_UNITS=0, **knobs)
+    lib = _native.lib()
+    rng = np.random.default_rng(4401)
+    # ---- one canvas per call: bands of pages (>= 64 pages each: 640 x 480 = 300 pages), transient and persistent
+    W, H = 640, 480
+    objs, pl = _scene(rng, 6, W, H, 14)
+    atlas = Atlas(objs, ctx=ctx)
+    rows = coerce_placements(atlas, pl)
+    for bg_kind in ("solid", "image", "unaligned"):
+        w = W - 3 if bg_kind == "unaligned" else W
+        if bg_kind == "image":
+            bg = rng.integers(0, 256, (H, w, 4), dtype=np.uint8)
+            canvas = torch.from_numpy(bg).cuda()
+        else:
+            bg = np.empty((H, w, 4), np.uint8)
+            bg[:] = (38, 73, 115, 255)
+            canvas = SolidCanvas((w, H), (38, 73, 115, 255))
+        want = oracle.composite(bg, objs, pl)
+        plan = CompositeBatch(atlas, [canvas], [rows])
+        st = plan.stats()
+        assert st["marched_layers"] >= 8
+        for rep in range(3):  # run 0 resamples (pipelined when the knobs say so), run 1 is resident, run 2 resamples again
+            if rep == 2:
+                plan.invalidate()
+            got = plan.run()[0].cpu().numpy()
+            assert np.array_equal(got, want), (knobs, bg_kind, rep)
+        if knobs.get("MIC_PIPE_BANDS", 1) > 1:
+            assert plan.stats()["pipeline_groups"] > 1, plan.stats()
+        del plan
+    # ---- several canvases per call: chunks of canvases, mixed kernel classes, shared and private layers
+    sizes = [(640, 200), (333, 300), (512, 256), (640, 200), (801, 120), (256, 512), (640, 200)]
+    if "MIC_PIPE_CHUNK" in knobs:
+        sizes = [(640, 200), (332, 300), (512, 256), (640, 200), (800, 120), (256, 512), (640, 200)]
+    pls, bgs, cvs = [], [], []
+    for i, (w, h) in enumerate(sizes):
+        q = _scene(rng, 6, w, h, int(rng.integers(3, 9)))[1]
+        # (the scene's object sizes are its own draw: re-draw boxes against THIS atlas' cutouts)
+        q = [{"object_id": p["object_id"], "box": [p["box"][0], p["box"][1], p["box"][0] + max(1, int(objs[p["object_id"]].shape[1] * (0.6 + 0.2 * (k % 5)))),
+                                                   p["box"][1] + max(1, int(objs[p["object_id"]].shape[0] * (0.6 + 0.2 * (k % 4))))]} for k, p in enumerate(q)]
+        pls.append(q)
+        # knobs with MIC_PIPE_CHUNK: one kernel class (opaque solid), so that the chunks' needs are a prefix of the
+        # resample order; the others: mixed classes (the table is sorted by class and the path may fall back to serial)
+        col = (38, 73, 115, 255) if (i % 2 == 0 or "MIC_PIPE_CHUNK" in knobs) else (9, 9, 200, 140)
+        bg = np.empty((h, w, 4), np.uint8)
+        bg[:] = col
+        bgs.append(bg)
+        cvs.append(SolidCanvas((w, h), col))
+    plan = CompositeBatch(atlas, cvs, [coerce_placements(atlas, q) for q in pls])
+    for rep in range(3):
+        if rep == 2:
+            plan.invalidate()
+        outs = plan.run()
+        for i, o in enumerate(outs):
+            assert np.array_equal(o.cpu().numpy(), oracle.composite(bgs[i], objs, pls[i])), (knobs, rep, i)
+    if knobs.get("MIC_PIPE_CHUNK", 0) > 0:
+        assert plan.stats()["pipeline_groups"] > 1, plan.stats()
+    del plan, atlas
+    assert lib.mic_destroy(ctx.handle) == 0
+
+
+def test_resident_layers_of_transient_calls(monkeypatch):
+    """mic_composite_batch twice with the same boxes: the second call finds every resampled layer in the context's cache
+    (cached_layers == the distinct resampled layers, no marching / tile work), moved boxes of the same size hit too,
+    another size misses, mic_layer_cache_clear forgets, another atlas never hits; pixels == oracle throughout."""
+    import torch
+    from image_transformation_amd import _native
+    from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
+    ctx = _ctx(monkeypatch)
+    lib = _native.lib()
+    rng = np.random.default_rng(4402)
+    W, H = 500, 300
+    objs, pl = _scene(rng, 5, W, H, 9)
+    atlas = Atlas(objs, ctx=ctx)
+    bg = np.empty((H, W, 4), np.uint8)
+    bg[:] = (220, 238, 245, 255)
+    cv = SolidCanvas((W, H), (220, 238, 245, 255))
+
+    def call(placements, a=atlas, o=objs):
+        got = composite_device(a, [cv], [coerce_placements(a, placements)])[0].cpu().numpy()
+        assert np.array_equal(got, oracle.composite(bg, o, placements))
+        return ctx.stats()
+
+    distinct = len({(p["object_id"], p["box"][2] - p["box"][0], p["box"][3] - p["box"][1]) for p in pl
+                    if (p["box"][2] - p["box"][0], p["box"][3] - p["box"][1]) != objs[p["object_id"]].shape[1::-1]})
+    s1 = call(pl)
+    assert s1["cached_layers"] == 0 and s1["resampled_layers"] > 0
+    s2 = call(pl)
+    assert s2["cached_layers"] == distinct
+    moved = [{"object_id": p["object_id"], "box": [p["box"][0] + 7, p["box"][1] - 5, p["box"][2] + 7, p["box"][3] - 5]} for p in pl]
+    assert call(moved)["cached_layers"] == distinct
+    grown = [{"object_id": p["object_id"], "box": [p["box"][0], p["box"][1], p["box"][2] + 1, p["box"][3]]} for p in pl]
+    assert call(grown)["cached_layers"] == 0
+    assert call(pl)["cached_layers"] == distinct
+    assert lib.mic_layer_cache_clear(ctx.handle) == 0
+    assert call(pl)["cached_layers"] == 0
+    objs2 = {k: np.ascontiguousarray(v[:, ::-1]) for k, v in objs.items()}  # the same ids and sizes, other pixels
+    atlas2 = Atlas(objs2, ctx=ctx)
+    assert call(pl, atlas2, objs2)["cached_layers"] == 0
+    assert call(pl, atlas2, objs2)["cached_layers"] == distinct
+    assert call(pl)["cached_layers"] == distinct  # the first atlas' layers are still there
+    del atlas, atlas2
+    assert lib.mic_destroy(ctx.handle) == 0
+
+
+def test_layer_cache_too_small_or_full(monkeypatch):
+    """MIC_LAYER_CACHE_MB=1: calls whose layers do not fit at once use the arena (no hits, right pixels); a sequence of
+    small calls fills the cache, which is then dropped and refilled; MIC_LAYER_CACHE_MB=0 turns it off."""
+    from image_transformation_amd import _native
+    from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
+    lib = _native.lib()
+    rng = np.random.default_rng(4403)
+    for mb in (1, 0):
+        ctx = _ctx(monkeypatch, MIC_LAYER_CACHE_MB=mb)
+        W, H = 700, 400
+        objs, _ = _scene(rng, 4, W, H, 1)
+        atlas = Atlas(objs, ctx=ctx)
+        bg = np.empty((H, W, 4), np.uint8)
+        bg[:] = (1, 2, 3, 255)
+        cv = SolidCanvas((W, H), (1, 2, 3, 255))
+        hits = []
+        for k in range(40):
+            oid = 1 + k % 4
+            sh, sw = objs[oid].shape[:2]
+            big = k % 10 == 9  # ~2.6 MB of layers in one call: more than the whole cache
+            w, h = (sw * 4, sh * 4) if big else (sw + 1 + k % 6, sh + 2)
+            pl = [{"object_id": oid, "box": [10, 10, 10 + w, 10 + h]}, {"object_id": oid, "box": [300, 150, 300 + w, 150 + h]}]
+            got = composite_device(atlas, [cv], [coerce_placements(atlas, pl)])[0].cpu().numpy()
+            assert np.array_equal(got, oracle.composite(bg, objs, pl)), (mb, k)
+            hits.append(ctx.stats()["cached_layers"])
+        if mb == 0:
+            assert sum(hits) == 0
+        else:
+            assert sum(hits) > 0 and all(h == 0 for k, h in enumerate(hits) if k % 10 == 9)
+        del atlas
+        assert lib.mic_destroy(ctx.handle) == 0
