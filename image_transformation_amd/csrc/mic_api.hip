@@ -203,6 +203,10 @@ struct mic_ctx {
     // hide (C3 placements canvas: 73 us serial, 98-430 us with 2-12 bands; 16 canvases per call: 58.7 us per canvas
     // serial, 63-107 us in chunks) -- whatever the event flags.  So both knobs default to the serial path; the groups
     // below are what the FUSED launches (kernels_fused.hip) are cut by instead.
+    // FUSED launches (kernels_fused.hip): in a call over several canvases with opaque solid backgrounds, the marching
+    // resample of chunk k + 1 and the composite of chunk k are two roles of ONE launch on the caller's stream -- no
+    // events, no second stream.  MIC_FUSE_CHUNK: canvases per chunk (0 = off).
+    int fuse_chunk = 2;
     int pipe_bands = 1;    // MIC_PIPE_BANDS: bands of a single-canvas call (<= 1: resample, then composite, on one stream)
     int pipe_chunk = 0;    // MIC_PIPE_CHUNK: canvases per chunk of a multi-canvas call (<= 0: serial)
     int pipe_streams = 1;  // MIC_PIPE_STREAMS: side streams the groups are dealt over (1: the groups run one after another)
@@ -290,6 +294,7 @@ extern "C" int mic_create(int device, mic_ctx **out) {
         }
     }
     if (const char *la = getenv("MIC_LAYER_ARGS")) ctx->layer_args = atoi(la) != 0;
+    if (const char *v = getenv("MIC_FUSE_CHUNK")) ctx->fuse_chunk = std::max(0, atoi(v));
     if (const char *v = getenv("MIC_PIPE_BANDS")) ctx->pipe_bands = std::max(1, std::min(64, atoi(v)));
     if (const char *v = getenv("MIC_PIPE_CHUNK")) ctx->pipe_chunk = std::max(0, atoi(v));
     if (const char *v = getenv("MIC_PIPE_STREAMS")) ctx->pipe_streams = std::max(1, std::min((int)mic_ctx::kSideStreams, atoi(v)));
@@ -1430,6 +1435,10 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     std::vector<Group> groups;
     const int n_fused = resident ? 0 : (int)P->pt.fused.size();
     const std::vector<PassTables::Mark> &marks = P->pt.marks;
+    // fused launches take canvases over an opaque solid background (kernel classes 0 and 1: every job of the table
+    // when class_end[1] == n_jobs); anything else may still be pipelined over side streams (off by default)
+    const bool fuse = !one && ctx->fuse_chunk > 0 && class_end[1] == n_jobs;
+    const int chunk = fuse ? ctx->fuse_chunk : ctx->pipe_chunk;
     if (n_fused > 0 && marks.size() > 1) {
         if (one && ctx->pipe_bands > 1) {
             const Job &d = P->ordered[0];
@@ -1449,12 +1458,12 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
                 groups.push_back({done, fe, p0, p1});
                 done = fe;
             }
-        } else if (!one && ctx->pipe_chunk > 0 && n_jobs > ctx->pipe_chunk) {
-            // chunks of pipe_chunk canvases in table order; the last chunk is cut in halves (.., 2, 1, 1) so that the
+        } else if (!one && chunk > 0 && n_jobs > chunk) {
+            // chunks of `chunk` canvases in table order; the last chunk is cut in halves (.., 2, 1, 1) so that the
             // composite nothing is left to hide is a small one
             std::vector<int> cuts;
             int at = 0;
-            while (n_jobs - at > ctx->pipe_chunk) { at += ctx->pipe_chunk; cuts.push_back(at); }
+            while (n_jobs - at > chunk) { at += chunk; cuts.push_back(at); }
             for (int rest = n_jobs - at; rest > 1; rest -= rest / 2) { at += rest / 2; cuts.push_back(at); }
             cuts.push_back(n_jobs);
             int a = 0, done = 0, need_job = -1;
@@ -1477,6 +1486,28 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
         HIP_TRY(launch_composite(jobs_dev, layers_dev, n_jobs, class_end, pitch, one ? &P->ordered[0] : nullptr,
                                  pack_layers ? P->layers.data() : nullptr, stream));
+    } else if (fuse) {
+        // resample(g0) | fused{resample(g1), composite(part 0)} | ... | composite(last part): one stream, no events
+        P->pipeline_groups = (int)groups.size();
+        const bool all_aligned = class_end[0] == n_jobs;
+        auto composite_part = [&](const Group &G) -> int {
+            int ce[3];
+            for (int c = 0; c < 3; ++c) ce[c] = std::min(std::max(class_end[c], G.a), G.b) - G.a;
+            HIP_TRY(launch_composite(jobs_dev + G.a, layers_dev, G.b - G.a, ce, pitch, nullptr, nullptr, stream));
+            return MIC_OK;
+        };
+        HIP_TRY(launch_resample_march(fused_dev + groups[0].fb, groups[0].fe - groups[0].fb, P->pt.lds_march, stream));
+        for (size_t g = 1; g < groups.size(); ++g) {
+            const Group &R = groups[g], &C = groups[g - 1];
+            if (R.fe > R.fb) {
+                HIP_TRY(launch_fused(fused_dev + R.fb, R.fe - R.fb, P->pt.lds_march, jobs_dev + C.a, layers_dev, C.b - C.a, pitch,
+                                     all_aligned, stream));
+            } else if (int rc = composite_part(C)) {
+                return rc;
+            }
+        }
+        if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
+        if (int rc = composite_part(groups.back())) return rc;
     } else {
         P->pipeline_groups = (int)groups.size();
         const int n_side = std::min(ctx->pipe_streams, (int)mic_ctx::kSideStreams);

@@ -160,6 +160,9 @@ struct alignas(16) PlanarJob {
 static_assert(sizeof(PlanarJob) == 32, "PlanarJob layout");
 hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream);
 hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, size_t lds_bytes, hipStream_t stream);
+// kernels_fused.hip: ONE launch = the marching resample of the next chunk of canvases + the composite of the previous one
+hipError_t launch_fused(const RsMarch *rs_jobs_dev, int n_rs, size_t lds_bytes, const Job *jobs_dev, const Layer *layers_dev,
+                        int n_jobs, int pitch, bool all_aligned, hipStream_t stream);
 hipError_t launch_resample_tile(const RsTile *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes, hipStream_t stream);
 // Known-answer canary of the clip / pack / (un)premultiply helpers (kernels_resample.hip): 0 mismatches expected.
 hipError_t run_selftest_clip(hipStream_t stream, int *mismatches, int *first_bad);

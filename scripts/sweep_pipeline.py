@@ -14,7 +14,7 @@ what = sys.argv[1] if len(sys.argv) > 1 else "all"
 W, H = 3840, 2160
 psize, pobjs, ppl = synthetic.placements_workload(W, H, 32, 3, "soft")
 sets = [ppl] + synthetic.placement_sets(pobjs, W, H, 3, 15)
-KNOBS = ("MIC_PIPE_BANDS", "MIC_PIPE_CHUNK", "MIC_PIPE_STREAMS", "MIC_PIPE_PRIO", "MIC_PIPE_EVFLAGS")
+KNOBS = ("MIC_FUSE_CHUNK", "MIC_PIPE_BANDS", "MIC_PIPE_CHUNK", "MIC_PIPE_STREAMS", "MIC_PIPE_PRIO", "MIC_PIPE_EVFLAGS")
 
 
 def make_ctx(**env):
@@ -61,20 +61,24 @@ if what in ("single", "all"):
         del plan, atlas, outs
         _native.lib().mic_destroy(ctx.handle)
 if what in ("batch", "all"):
-    for chunk, streams, prio, evf in [(0, 1, 0, "2")] + [(c, s, 0, f) for f in EVF for c in (2, 4) for s in (1, 2)]:
-        ctx = make_ctx(MIC_PIPE_CHUNK=chunk, MIC_PIPE_STREAMS=streams, MIC_PIPE_PRIO=prio, MIC_PIPE_EVFLAGS=evf)
-        atlas = Atlas(pobjs, ctx=ctx)
-        plan = CompositeBatch(atlas, [SolidCanvas(psize, synthetic.SOLID_BG)] * 16, [coerce_placements(atlas, q) for q in sets])
-        outs = plan.alloc_outputs()
-        med, best = span_us(plan, outs, 12)
-        got = [o.cpu().numpy() for o in plan.run(outs)]
-        h = [hash(g.tobytes()) for g in got]
-        if ref_batch is None: ref_batch = h
-        warm = span_us(plan, outs, 10, cold=False)
-        rows.append(dict(mode="batch16", evflags=evf, chunk=chunk, streams=streams, prio=prio, cold_us_per_canvas=round(med / 16, 2),
-                         cold_best_us_per_canvas=round(best / 16, 2), warm_us_per_canvas=round(warm[0] / 16, 2),
-                         groups=plan.stats()["pipeline_groups"], same_pixels=h == ref_batch))
-        print(json.dumps(rows[-1]), flush=True)
-        del plan, atlas, outs, got
-        _native.lib().mic_destroy(ctx.handle)
+    for nb in (16, 4):
+        for fuse in (0, 1, 2, 3, 4, 8):
+            if fuse >= nb: continue
+            ctx = make_ctx(MIC_FUSE_CHUNK=fuse, MIC_PIPE_CHUNK=0)
+            atlas = Atlas(pobjs, ctx=ctx)
+            plan = CompositeBatch(atlas, [SolidCanvas(psize, synthetic.SOLID_BG)] * nb, [coerce_placements(atlas, q) for q in sets[:nb]])
+            outs = plan.alloc_outputs()
+            med, best = span_us(plan, outs, 12)
+            plan.invalidate()
+            got = [o.cpu().numpy() for o in plan.run(outs)]
+            groups = plan.stats()["pipeline_groups"]
+            h = [hash(g.tobytes()) for g in got]
+            if fuse == 0: ref_batch = h
+            warm = span_us(plan, outs, 10, cold=False)
+            rows.append(dict(mode=f"batch{nb}", fuse_chunk=fuse, cold_us_per_canvas=round(med / nb, 2),
+                             cold_best_us_per_canvas=round(best / nb, 2), warm_us_per_canvas=round(warm[0] / nb, 2),
+                             groups=groups, same_pixels=h == ref_batch))
+            print(json.dumps(rows[-1]), flush=True)
+            del plan, atlas, outs, got
+            _native.lib().mic_destroy(ctx.handle)
 print("SWEEP_DONE", len(rows))

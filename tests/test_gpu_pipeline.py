@@ -16,7 +16,7 @@ import cases  # noqa: E402
 import oracle  # noqa: E402
 
 P = ctypes.c_void_p
-KNOBS = ("MIC_PIPE_BANDS", "MIC_PIPE_CHUNK", "MIC_PIPE_STREAMS", "MIC_PIPE_PRIO", "MIC_RS_MARCH_MIN_UNITS", "MIC_LAYER_CACHE_MB")
+KNOBS = ("MIC_FUSE_CHUNK", "MIC_PIPE_BANDS", "MIC_PIPE_CHUNK", "MIC_PIPE_STREAMS", "MIC_PIPE_PRIO", "MIC_RS_MARCH_MIN_UNITS", "MIC_LAYER_CACHE_MB")
 
 
 def _ctx(monkeypatch, **env):
@@ -44,9 +44,11 @@ def _scene(rng, n_obj, W, H, n_layers, alpha="soft"):
     return objs, pl
 
 
-@pytest.mark.parametrize("knobs", [dict(MIC_PIPE_BANDS=1, MIC_PIPE_CHUNK=0), dict(MIC_PIPE_BANDS=3), dict(MIC_PIPE_BANDS=8, MIC_PIPE_STREAMS=3),
-                                   dict(MIC_PIPE_BANDS=4, MIC_PIPE_STREAMS=2, MIC_PIPE_PRIO=1), dict(MIC_PIPE_CHUNK=1, MIC_PIPE_STREAMS=2),
-                                   dict(MIC_PIPE_CHUNK=3, MIC_PIPE_STREAMS=3, MIC_PIPE_PRIO=1)])
+@pytest.mark.parametrize("knobs", [dict(MIC_FUSE_CHUNK=0), dict(), dict(MIC_FUSE_CHUNK=1), dict(MIC_FUSE_CHUNK=3),
+                                   dict(MIC_FUSE_CHUNK=0, MIC_PIPE_BANDS=3), dict(MIC_FUSE_CHUNK=0, MIC_PIPE_BANDS=8, MIC_PIPE_STREAMS=3),
+                                   dict(MIC_FUSE_CHUNK=0, MIC_PIPE_BANDS=4, MIC_PIPE_STREAMS=2, MIC_PIPE_PRIO=1),
+                                   dict(MIC_FUSE_CHUNK=0, MIC_PIPE_CHUNK=1, MIC_PIPE_STREAMS=2),
+                                   dict(MIC_FUSE_CHUNK=0, MIC_PIPE_CHUNK=3, MIC_PIPE_STREAMS=3, MIC_PIPE_PRIO=1)])
 def test_pipelined_path_matches_the_oracle(knobs, monkeypatch):
     import torch
     from image_transformation_amd import _native
@@ -80,34 +82,48 @@ def test_pipelined_path_matches_the_oracle(knobs, monkeypatch):
         if knobs.get("MIC_PIPE_BANDS", 1) > 1:
             assert plan.stats()["pipeline_groups"] > 1, plan.stats()
         del plan
-    # ---- several canvases per call: chunks of canvases, mixed kernel classes, shared and private layers
-    sizes = [(640, 200), (333, 300), (512, 256), (640, 200), (801, 120), (256, 512), (640, 200)]
-    if "MIC_PIPE_CHUNK" in knobs:
-        sizes = [(640, 200), (332, 300), (512, 256), (640, 200), (800, 120), (256, 512), (640, 200)]
-    pls, bgs, cvs = [], [], []
-    for i, (w, h) in enumerate(sizes):
-        q = _scene(rng, 6, w, h, int(rng.integers(3, 9)))[1]
-        # (the scene's object sizes are its own draw: re-draw boxes against THIS atlas' cutouts)
-        q = [{"object_id": p["object_id"], "box": [p["box"][0], p["box"][1], p["box"][0] + max(1, int(objs[p["object_id"]].shape[1] * (0.6 + 0.2 * (k % 5)))),
-                                                   p["box"][1] + max(1, int(objs[p["object_id"]].shape[0] * (0.6 + 0.2 * (k % 4))))]} for k, p in enumerate(q)]
-        pls.append(q)
-        # knobs with MIC_PIPE_CHUNK: one kernel class (opaque solid), so that the chunks' needs are a prefix of the
-        # resample order; the others: mixed classes (the table is sorted by class and the path may fall back to serial)
-        col = (38, 73, 115, 255) if (i % 2 == 0 or "MIC_PIPE_CHUNK" in knobs) else (9, 9, 200, 140)
-        bg = np.empty((h, w, 4), np.uint8)
-        bg[:] = col
-        bgs.append(bg)
-        cvs.append(SolidCanvas((w, h), col))
-    plan = CompositeBatch(atlas, cvs, [coerce_placements(atlas, q) for q in pls])
-    for rep in range(3):
-        if rep == 2:
-            plan.invalidate()
-        outs = plan.run()
-        for i, o in enumerate(outs):
-            assert np.array_equal(o.cpu().numpy(), oracle.composite(bgs[i], objs, pls[i])), (knobs, rep, i)
-    if knobs.get("MIC_PIPE_CHUNK", 0) > 0:
-        assert plan.stats()["pipeline_groups"] > 1, plan.stats()
-    del plan, atlas
+    # ---- several canvases per call: chunks of canvases.  Scene A: every canvas over an opaque solid background (the
+    # fused launches' class; aligned and unaligned widths) -- the chunks' needs are a prefix of the resample order and
+    # the call IS cut into groups; scene B: mixed kernel classes (the table is sorted by class: serial fallback allowed)
+    chunked = knobs.get("MIC_FUSE_CHUNK", 2) > 0 or knobs.get("MIC_PIPE_CHUNK", 0) > 0
+    for scene in ("A", "B"):
+        sizes = [(640, 200), (332, 300), (512, 256), (640, 200), (800, 120), (256, 512), (640, 200), (333, 210), (801, 64)]
+        if scene == "A" and knobs.get("MIC_FUSE_CHUNK", 2) == 3:
+            sizes = sizes[:7]  # all aligned: the <ALIGNED = true> instantiation of the fused kernel
+        pls, bgs, cvs = [], [], []
+        for i, (w, h) in enumerate(sizes):
+            q = []
+            for k in range(int(rng.integers(3, 9))):
+                oid = int(rng.integers(1, 7))
+                sh, sw = objs[oid].shape[:2]
+                bw, bh = max(1, int(sw * (0.6 + 0.2 * (k % 5)))), max(1, int(sh * (0.6 + 0.2 * (k % 4))))
+                if k % 4 == 3:
+                    bw, bh = sw, sh  # an identity-scale layer among the resampled ones
+                x1, y1 = int(rng.integers(-bw // 3, w - bw // 2)), int(rng.integers(-bh // 3, h - bh // 2))
+                q.append({"object_id": oid, "box": [x1, y1, x1 + bw, y1 + bh]})
+            pls.append(q)
+            col = (38, 73, 115, 255) if (scene == "A" or i % 2 == 0) else (9, 9, 200, 140)
+            bg = np.empty((h, w, 4), np.uint8)
+            bg[:] = col
+            bgs.append(bg)
+            cvs.append(SolidCanvas((w, h), col))
+        plan = CompositeBatch(atlas, cvs, [coerce_placements(atlas, q) for q in pls])
+        for rep in range(3):
+            if rep == 2:
+                plan.invalidate()
+            outs = plan.run()
+            for i, o in enumerate(outs):
+                assert np.array_equal(o.cpu().numpy(), oracle.composite(bgs[i], objs, pls[i])), (knobs, scene, rep, i)
+        if chunked and scene == "A":
+            assert plan.stats()["pipeline_groups"] > 1, plan.stats()
+        # the same canvases through the transient entry point (tables through the staging ring, layers in the cache)
+        from image_transformation_amd.compositor import composite_device
+        for rep in range(2):
+            outs = composite_device(atlas, cvs, [coerce_placements(atlas, q) for q in pls])
+            for i, o in enumerate(outs):
+                assert np.array_equal(o.cpu().numpy(), oracle.composite(bgs[i], objs, pls[i])), (knobs, scene, "transient", rep, i)
+        del plan
+    del atlas
     assert lib.mic_destroy(ctx.handle) == 0
 
 
