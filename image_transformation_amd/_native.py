@@ -53,7 +53,7 @@ class ImageView(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint64) for n in
                 ("canvas_pixels", "layer_pixels", "source_pixels", "resampled_layers", "identity_layers",
-                 "skipped_placements", "composite_blocks", "marched_layers", "cached_layers", "pipeline_groups")]
+                 "skipped_placements", "composite_blocks", "marched_layers", "cached_layers")]
 
     def as_dict(self) -> Dict[str, int]:
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

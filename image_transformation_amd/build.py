@@ -14,11 +14,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmic.so")
-SOURCES = ["mic_api.hip", "kernels_composite.hip", "kernels_resample.hip", "kernels_fused.hip", "kernels_resample_tile.hip",
-           "kernels_median.hip", "kernels_overlay.hip",
+SOURCES = ["mic_api.hip", "kernels_composite.hip", "kernels_resample.hip", "kernels_resample_tile.hip", "kernels_median.hip",
+           "kernels_overlay.hip",
            "resample_coeffs.cpp", "flex_place.cpp", "png_encode.cpp"]
-HEADERS = ["mic_internal.h", "composite_device.h", "composite_body.inc", "resample_device.h", "resample_march_body.inc",
-           "resample_coeffs.h", "flex_place.h", "png_encode.h", os.path.join("..", "..", "include", "mic.h")]
+HEADERS = ["mic_internal.h", "resample_coeffs.h", "flex_place.h", "png_encode.h", os.path.join("..", "..", "include", "mic.h")]
 ARCH = "gfx950"
 
 

@@ -12,9 +12,83 @@
 #include <algorithm>
 #include <atomic>
 
-#include "resample_device.h"
+#include "mic_internal.h"
 
 namespace mic {
+
+__device__ __forceinline__ uint32_t div255_shift(uint32_t t) { return ((t >> 8) + t) >> 8; }
+
+__device__ __forceinline__ uint32_t premultiply(uint32_t p) {
+    const uint32_t a = p >> 24;
+    const uint32_t r = div255_shift((p & 255u) * a + 128u);
+    const uint32_t g = div255_shift(((p >> 8) & 255u) * a + 128u);
+    const uint32_t b = div255_shift(((p >> 16) & 255u) * a + 128u);
+    return r | (g << 8) | (b << 16) | (a << 24);
+}
+
+// Convert.c rgba2rgbA: c = min(255, 255*c' / a) for 0 < a < 255.  The integer division is replaced
+// by one v_mul_hi_u32 with R[a] = ceil(255 * 2^24 / a): floor(c' * R[a] / 2^24) == floor(255*c'/a)
+// exactly for c' in 0..255 (the excess is < 2^-16, the quotient's fractional part is a multiple
+// of 1/a <= 1 - 1/254); checked exhaustively in tests/test_blend_identities.py.
+struct UnpremulTable {
+    uint32_t r[256];
+    constexpr UnpremulTable() : r{} {
+        for (uint32_t a = 1; a < 256; ++a) r[a] = (uint32_t)((((uint64_t)255 << 24) + a - 1) / a);
+    }
+};
+__device__ __constant__ UnpremulTable kUnpremul{};
+
+__device__ __forceinline__ uint32_t unpremultiply(uint32_t p) {
+    const uint32_t a = p >> 24;
+    if (a == 0u || a == 255u) return p;
+    const uint32_t R = kUnpremul.r[a];
+    const uint32_t r = min(255u, __umulhi((p & 255u) << 8, R));
+    const uint32_t g = min(255u, __umulhi(p & 0xFF00u, R));
+    const uint32_t b = min(255u, __umulhi((p >> 8) & 0xFF00u, R));
+    return r | (g << 8) | (b << 16) | (a << 24);
+}
+
+// The same in float, for the MFMA kernel (v_mul_hi_u32 is a quarter-rate instruction, and this runs
+// once per output pixel): floor(c' * F[a]) == floor(255 c' / a) for every c' in 0..255 once clamped to
+// 255, with F[a] = 255/a rounded to float and bumped up one ulp -- the product can only exceed the
+// exact quotient, by < 2^-14, and the quotient's fractional part is <= 1 - 1/254 (or the value is
+// >= 256 and clamps).  Checked exhaustively in tests/test_blend_identities.py with numpy float32.
+__device__ __forceinline__ float unpremul_factor(uint32_t a) {
+    return __uint_as_float(__float_as_uint(__fdiv_rn(255.0f, (float)a)) + 1u);
+}
+__device__ __forceinline__ uint32_t unpremultiply_with(uint32_t p, const float *table) {
+    const uint32_t a = p >> 24;
+    if (a == 0u || a == 255u) return p;
+    const float F = table[a];
+    const uint32_t r = min(255u, (uint32_t)((float)(p & 255u) * F));
+    const uint32_t g = min(255u, (uint32_t)((float)((p >> 8) & 255u) * F));
+    const uint32_t b = min(255u, (uint32_t)((float)((p >> 16) & 255u) * F));
+    return r | (g << 8) | (b << 16) | (a << 24);
+}
+
+__device__ __forceinline__ uint32_t clip8(int32_t v) {
+    v >>= kPrecisionBits;  // arithmetic shift, like Pillow's clip8 lookup index
+    // hipcc (ROCm 7.2, gfx950) fuses "shift, clamp to 0..255, pack" into v_ashr_pk_u8_i32 and then
+    // ORs the 16-bit result as if the destination's upper half were zero; it is not (the
+    // instruction only writes D[15:0]), which corrupted blue/alpha on the MI355X.  The empty asm
+    // keeps the shift and the clamp apart so the clamp lowers to v_med3_i32.
+    asm volatile("" : "+v"(v));
+    return (uint32_t)min(255, max(0, v));
+}
+
+// acc += channel * tap for the four channels of one pixel.  Both factors fit 24 bits (bytes; taps
+// are 22-bit fixed point, |k| < 2^23), so v_mad_i32_i24 is exact -- and is what must be asked for:
+// a plain int32 multiply-add made hipcc emit 64-bit v_mad_u64_u32, several times slower.
+__device__ __forceinline__ void mac4(int32_t &s0, int32_t &s1, int32_t &s2, int32_t &s3, uint32_t p, int32_t k) {
+    s0 += __mul24((int)(p & 255u), k);
+    s1 += __mul24((int)((p >> 8) & 255u), k);
+    s2 += __mul24((int)((p >> 16) & 255u), k);
+    s3 += __mul24((int)(p >> 24), k);
+}
+
+__device__ __forceinline__ uint32_t pack_clip(int32_t s0, int32_t s1, int32_t s2, int32_t s3) {
+    return clip8(s0) | (clip8(s1) << 8) | (clip8(s2) << 16) | (clip8(s3) << 24);
+}
 
 // Horizontal pass: one thread per output pixel (x', y).  Coefficients are stored TRANSPOSED
 // ([ksize][out_w]) so that the 64 lanes of a wave read consecutive words for each tap.
@@ -64,6 +138,110 @@ __global__ __launch_bounds__(256) void resample_v_kernel(const RsJob *__restrict
     reinterpret_cast<gptr>(J.dst)[(size_t)yy * J.out_w + x] = o;
 }
 
+// Fused resize on the matrix cores, marching down column strips.
+//
+// A separable resample is a banded matrix product per axis -- out = in x K^T with K[x][k] the taps
+// of output sample x -- and it is exact integer arithmetic, so it maps onto v_mfma_i32_16x16x64_i8
+// without touching the result: the 8-bit samples are stored as signed bytes (s - 128, the constant
+// 128 * sum(taps) goes into the accumulator's initial value together with Pillow's 2^21 rounding
+// term) and each 22-bit tap is split into three signed-byte digits, c = d0 + 256 d1 + 65536 d2.
+// The three digit products are not summed afterwards; they are CHAINED through the accumulator:
+//     acc = mfma(data, d0, bias);  acc >>= 8;  acc = mfma(data, d1, acc);  acc >>= 8;
+//     acc = mfma(data, d2, acc);   out = sat8(acc >> 6)
+// which is Pillow's clip8((bias + sum) >> 22) exactly, because floor((x + floor(y / n)) / m) ==
+// floor((x + y / n) / m) for integers x, y and positive n, m (arithmetic shifts are floor divisions).
+// Two plain shifts per value replace the shift-adds of a digit recombination, and a channel needs one
+// 4-register accumulator instead of three -- registers are what decides this kernel: it is bound by
+// vector issue (profiles/r02_ubench_isa.txt: one wave alone issues a VALU instruction every ~8 cycles,
+// four waves per SIMD are needed to approach the 2-cycle rate, the matrix pipe takes ~10), so the
+// design goal is many resident waves, few instructions per value.
+//
+// Work unit = one workgroup (4 waves) = a column strip of 64 output columns x `seg_tiles` tiles of 16
+// output rows of one layer; wave w owns the strip's x-tile w for both passes.  The unit marches down
+// the source in bands of 16 rows:
+//   1. the band's rows x the strip's column window come from the cutout's planar premultiplied copy
+//      (planarize_kernel) into LDS, 16 bytes per lane, prefetched one band ahead in registers;
+//   2. horizontal pass (wave w: 16 rows x 16 outputs of x-tile w, taps resident in registers) -> clip ->
+//      the 8-bit intermediate Pillow keeps between its passes, into the wave's PRIVATE ring of
+//      intermediate rows ([channel][x][ring row], 16-row slots), so the only workgroup barriers are the
+//      two around the shared source band;
+//   3. every tile of 16 output rows whose last tap row is now in the ring: vertical pass with the ring
+//      as the A operand (M = x), so a lane ends up with 4 horizontally adjacent pixels of one output row
+//      -> unpremultiply -> one 16-byte store.
+// Neither the source rows nor the horizontal pass are redone for vertical neighbours inside a unit (the
+// 64 x 64-tile version of round 1 re-read 2.1x the source and redid 25-40% of the horizontal pass).
+// Bands whose window holds no pixel of alpha > 0 (the corners around a cutout's shape) skip the
+// horizontal pass, and output tiles that only see such bands are stored as transparent black.
+// The k index of both operands is defined by the same (lane >> 4, byte) -> window position map, so
+// the result does not depend on the hardware's internal k order; C/D follow the documented
+// col = lane & 15, row = 4 (lane >> 4) + reg map.  Bit-exact with the two-pass kernels above.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) v4i *gv4ptr;
+typedef u32x4 __attribute__((aligned(4))) u32x4_a4;  // 16-byte access, 4-byte alignment
+
+// v_perm_b32: result byte i = byte sel[i] of the 8-byte value {hi (bytes 4..7), lo (bytes 0..3)}.
+__device__ __forceinline__ uint32_t byte_perm(uint32_t hi, uint32_t lo, uint32_t sel) {
+    return __builtin_amdgcn_perm(hi, lo, sel);
+}
+
+// Convert.c rgbA2rgba on two channels at once: x holds two bytes in 16-bit lanes (0x00XX00YY); the
+// two results div255(c * a + 128) = (t + (t >> 8)) >> 8 are left in BYTES 1 AND 3 of the returned
+// word (bytes 0 and 2 are rounding residue) -- the planarising v_perm picks them from there, which
+// saves the final shift+mask.  No lane can carry into the other: c * a + 128 <= 65153 and adding
+// (t >> 8) <= 254 stays below 65536.  Three instructions for two channels.
+__device__ __forceinline__ uint32_t premultiply2_hi(uint32_t x, uint32_t a) {
+    const uint32_t t = __umul24(x, a) + 0x00800080u;            // v_mad_u32_u24
+    return t + byte_perm(t, t, 0x0c030c01u);                     // + {t.b1, 0, t.b3, 0}
+}
+
+// sat8(v >> 6) of the four sums of an accumulator -> four bytes of one word, byte i from v[i].
+// v_ashr_pk_u8_i32 shifts, saturates to 0..255 and packs two values per instruction into D[15:0].  It is
+// issued through the compiler's builtin, not inline asm: the values come straight out of an MFMA, and the
+// wait states between an MFMA and a VALU read of its result are inserted by the compiler's hazard
+// recogniser, which does not look inside asm statements (an asm version read the accumulator early and
+// produced saturated garbage).  The builtin returns 16 bits, so the upper half's stale bits -- what
+// hipcc's own pattern-matched use of the instruction gets wrong, see clip8 -- are dropped explicitly.
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t clip8x4(v4i v) {
+    // (two 16-bit halves built as a vector: the compiler then gathers them with ONE v_perm_b32; widening the
+    // halves to 32 bits first costs a mask each)
+    const u16x2 p = {__builtin_amdgcn_ashr_pk_u8_i32(v[0], v[1], 6), __builtin_amdgcn_ashr_pk_u8_i32(v[2], v[3], 6)};
+    return __builtin_bit_cast(uint32_t, p);
+}
+// The same with SIGNED saturation to -128..127: with 128 << 22 taken off the bias beforehand this is
+// clip8(...) - 128, the signed-byte form the next pass' MFMA operand wants (clamp(x, 0, 255) - 128 ==
+// clamp(x - 128, -128, 127)), without the xor 0x80 per word.
+__device__ __forceinline__ uint32_t clip8x4_signed(v4i v) {
+    const u16x2 p = {__builtin_amdgcn_ashr_pk_i8_i32(v[0], v[1], 6), __builtin_amdgcn_ashr_pk_i8_i32(v[2], v[3], 6)};
+    return __builtin_bit_cast(uint32_t, p);
+}
+
+__device__ __forceinline__ v4i shr8(v4i v) { return v4i{v[0] >> 8, v[1] >> 8, v[2] >> 8, v[3] >> 8}; }
+
+// One 16 x 16 tile of all four channels through the digit chain -> per channel one word of clipped bytes.
+// load(c) returns the data operand (A) of channel c, f = the tile's tap digits (B).  The four channels' chains
+// are written side by side: each MFMA's result is needed three MFMAs later, so the dependent shifts need no
+// s_nop padding.  SIGNED: clip to signed bytes (the horizontal pass, see clip8x4_signed).
+template <bool SIGNED, class Load>
+__device__ __forceinline__ void tile4(Load load, const v4i (&f)[3], v4i bias, uint32_t (&w)[4]) {
+    v4i a[4], acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a[c] = load(c);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[c], f[d], d == 0 ? bias : acc[c], 0, 0, 0);
+        if (d < 2) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = shr8(acc[c]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] = SIGNED ? clip8x4_signed(acc[c]) : clip8x4(acc[c]);
+}
+
 // ---- resident planar copy of an atlas ------------------------------------------------------------
 // Premultiplying and planarising a cutout is a pure function of the cutout, and the atlas stays
 // resident across composites / refine iterations / batches: the first resample that touches an atlas
@@ -108,13 +286,236 @@ hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_i
     return hipGetLastError();
 }
 
+// Convert.c rgba2rgbA on the four pixels a lane holds after the vertical pass, straight from the
+// per-channel words (w[c] = channel c of pixels 0..3): c = min(255, floor(255 c' / a)) for 0 < a < 255,
+// the pixel as it is for a = 0 and a = 255.  Per channel one v_cvt_f32_ubyteN (which also picks the
+// byte), one fma and one v_cvt_pk_u8_f32 (round to nearest even, saturating, written into byte c of the
+// pixel word: profiles/r02_ubench_isa.txt), so the planar -> interleaved transposition costs nothing:
+//     RNE(c' * F[a] - 0.5 + 2^-9) == floor(255 c' / a)   whenever that is < 256, and >= 255.5 otherwise,
+// with F[a] = 255/a rounded to float and bumped up one ulp, F[0] = F[255] = 1 (then it returns c'):
+// the product exceeds the exact quotient by < 2^-13, the quotient's fractional part is a multiple of
+// 1/a <= 1 - 1/254, and 2^-9 sits strictly between the two.  Checked exhaustively over (a, c') in
+// tests/test_blend_identities.py with float32 arithmetic.
+__device__ __forceinline__ u32x4 unpremultiply4(const uint32_t (&w)[4], const float *recip) {
+    const float K = -0.5f + 0.001953125f;
+    u32x4 px;
+#define MIC_UNPREMUL_PX(X)                                                                              \
+    {                                                                                                   \
+        const uint32_t a = (w[3] >> (8 * X)) & 255u;                                                    \
+        const float F = recip[a];                                                                       \
+        uint32_t p = a << 24;                                                                           \
+        p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)((w[0] >> (8 * X)) & 255u), F, K), 0, p); \
+        p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)((w[1] >> (8 * X)) & 255u), F, K), 1, p); \
+        p = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf((float)((w[2] >> (8 * X)) & 255u), F, K), 2, p); \
+        px[X] = p;                                                                                      \
+    }
+    MIC_UNPREMUL_PX(0) MIC_UNPREMUL_PX(1) MIC_UNPREMUL_PX(2) MIC_UNPREMUL_PX(3)
+#undef MIC_UNPREMUL_PX
+    return px;
+}
+
+// The same four pixels when no lane of the wave holds a partial alpha: a 4 x 4 byte transpose.
+__device__ __forceinline__ u32x4 interleave4(const uint32_t (&w)[4]) {
+    const uint32_t rg01 = byte_perm(w[1], w[0], 0x05010400u), rg23 = byte_perm(w[1], w[0], 0x07030602u);
+    const uint32_t ba01 = byte_perm(w[3], w[2], 0x05010400u), ba23 = byte_perm(w[3], w[2], 0x07030602u);
+    return u32x4{byte_perm(ba01, rg01, 0x05040100u), byte_perm(ba01, rg01, 0x07060302u),
+                 byte_perm(ba23, rg23, 0x05040100u), byte_perm(ba23, rg23, 0x07060302u)};
+}
+
+// uniform 64-bit base + 32-bit per-lane byte offset, written as pointer arithmetic so that the load takes
+// the scalar-base addressing form (global_load v, v_off, s[base:base+1]) instead of 64-bit vector address maths
+template <class T>
+__device__ __forceinline__ const MIC_GLOBAL T *at(uint64_t base, uint32_t byte_off) {
+    return reinterpret_cast<const MIC_GLOBAL T *>(reinterpret_cast<const MIC_GLOBAL char *>(base) + byte_off);
+}
+
 // Every tile of both axes of a layer that comes here has its taps inside ONE 64-sample window (any scale down to
 // ~1/3: the host checks it per layer; deeper shrinks, single images and small calls take the tile kernel of
 // kernels_resample_tile.hip) -- no chunk loops, their registers or their branches.
 __global__ __launch_bounds__(256, MIC_RS_WAVES) void resample_march_kernel(const RsMarch *__restrict__ jobs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
+    __shared__ float recip[256];            // unpremultiply factors 255/a: an LDS read per pixel
+    __shared__ v4i vm_lds[kRsMaxSegTiles];  // the unit's vertical tile table
+    __shared__ uint32_t band_alpha;         // does the band in LDS hold a pixel of alpha > 0
     const RsMarch J = jobs[blockIdx.y];
-    const int bx = (int)blockIdx.x, tid = threadIdx.x;
-#include "resample_march_body.inc"
+    // XCD-aware unit order (see RsMarch): blockIdx.x & 7 is the XCD this workgroup lands on
+    const int unit = (((int)blockIdx.x + J.xcd_rot) & 7) * (4 * J.n_entries) + 4 * J.entry + ((int)blockIdx.x >> 3);
+    if (unit >= J.strips * J.segs) return;
+    const int seg = unit / J.strips, strip = unit - seg * J.strips;
+    const int xt0 = strip * 4, n_xt = min(4, J.tiles_x - xt0);
+    const int yt0 = seg * J.seg_tiles, n_yt = min(J.seg_tiles, J.tiles_y - yt0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lh = lane >> 4;
+
+    gv4ptr hmeta = reinterpret_cast<gv4ptr>(J.hmeta), vmeta = reinterpret_cast<gv4ptr>(J.vmeta);
+    recip[tid] = (tid == 0 || tid == 255) ? 1.0f : unpremul_factor((uint32_t)tid);
+    if (tid < n_yt) vm_lds[tid] = vmeta[yt0 + tid];
+    const int c_lo = hmeta[xt0][0];  // the strip's first source column (a multiple of 16)
+    // 16-byte column chunks of a band: what the strip's tiles can touch, inside the cutout's padded rows
+    const int n16 = min(J.pitch_c >> 4, (J.planar_pitch - c_lo) >> 4);
+    const int plane_s = 16 * J.pitch_c;
+    uint8_t *srcP = lds8;                 // [4][16][pitch_c]     the source band
+    // intermediate rows: [x 64][ring16 slots of 16 rows][channel 4][16 rows] -- the four channels of a slot lie 16
+    // bytes apart, so one address register serves all four (instruction offsets); a column is pitch_r =
+    // 64 ring16 + 16 bytes (the 16 spread the columns over the banks)
+    uint8_t *ring = lds8 + 4 * plane_s;
+    const int rmask = J.ring16 - 1;
+    const int band0 = vmeta[yt0][0] >> 4;                  // window starts are multiples of 16
+    const int band_last = (vmeta[yt0 + n_yt - 1][3] - 1) >> 4;
+
+    // ---- this wave's x-tile: horizontal taps stay in registers for the whole unit
+    const bool active = wave < n_xt;  // wave-uniform
+    const int xt = xt0 + (active ? wave : 0);
+    const v4i hm_v = hmeta[xt];  // the same for every lane: kept in scalar registers
+    const int hm[3] = {__builtin_amdgcn_readfirstlane(hm_v[0]), __builtin_amdgcn_readfirstlane(hm_v[1]),
+                       __builtin_amdgcn_readfirstlane(hm_v[2])};
+    const uint32_t lane16 = (uint32_t)lane * 16u, l15x4 = (uint32_t)l15 * 4u;
+    // (- 128 << 22: the horizontal pass clips to signed bytes, see clip8x4_signed)
+    const int hb = *at<int32_t>(J.hbias + (uint64_t)xt * 64, l15x4) - (128 << 22);
+    const v4i hbias = {hb, hb, hb, hb};
+    // (uniform 64-bit base + 32-bit lane offset: the loads take the scalar-base addressing form, no 64-bit
+    // vector address arithmetic)
+    const uint64_t hfb = J.hfrag + (uint64_t)hm[2] * 3072;
+    gv4ptr hfbase = at<v4i>(hfb, lane16);
+    const v4i hf[3] = {hfbase[0], hfbase[64], hfbase[128]};
+    const uint8_t *a0 = srcP + l15 * J.pitch_c + (hm[0] - c_lo) + 16 * lh;
+    uint8_t *m0 = ring + (wave * 16 + l15) * J.pitch_r + 4 * lh;  // + 64 slot + 16 c
+    const uint8_t *r0 = ring + (wave * 16 + l15) * J.pitch_r;     // + 64 slot + 16 c
+    gptr dst = reinterpret_cast<gptr>(J.dst);
+    const int ox = (xt0 + wave) * 16 + 4 * lh;
+    const bool x_full = (xt0 + wave) * 16 + 16 <= J.dw;   // wave-uniform: every lane's 4 pixels are inside the row
+    const uint32_t lane_idx = (uint32_t)(l15 * J.dw + ox);  // pixel index of this lane inside a tile of output rows
+    const bool ox_ok = ox < J.dw;
+
+    // ---- band loader: wave = plane, lane = (row, chunk mod 4); chunks cl, cl + 4, ... < n16
+    const int lrow = lane >> 2, cl = lane & 3;
+    const uint64_t gplane = J.src + (uint64_t)wave * ((uint64_t)J.planar_pitch * J.sh) + c_lo;  // uniform
+    uint8_t *lds_dst = srcP + wave * plane_s + lrow * J.pitch_c + 16 * cl;
+    v4i pre[2];
+    // byte offset of this lane's first chunk of band b inside the plane (a plane is < 2^31 bytes)
+    auto band_off = [&](int b) { return (uint32_t)min(16 * b + lrow, J.sh - 1) * (uint32_t)J.planar_pitch + 16u * cl; };
+    auto prefetch = [&](int b) {
+        const uint32_t o = band_off(b);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (cl + 4 * k < n16) pre[k] = *at<v4i>(gplane, o + 64u * k);
+    };
+    prefetch(band0);
+
+    int yt = 0;           // next tile of output rows (relative to yt0) to emit ...
+    int v_ws = 0, v_hi = 0;  // ... and its window (first source row, one past the last)
+    // Its taps and bias wait in REGISTERS: they are fetched as soon as the tile before it has issued its last MFMA,
+    // ahead of that tile's epilogue and stores -- a tile's tap loads sit most of a tile (often a whole band) ahead of
+    // their use, and the in-order vmcnt wait for them does not cover the stores issued after them.  (One register
+    // set, reloaded in place: two alternating sets made hipcc merge the two copies of the tile code again and copy
+    // one set into the other behind a vmcnt(0).)
+    v4i vf[3];
+    int vb = 0;
+    auto fetch_taps = [&](int frag, int row0) __attribute__((always_inline)) {
+        vb = *at<int32_t>(J.vbias + (uint64_t)row0 * 4, l15x4);
+        gv4ptr vfbase = at<v4i>(J.vfrag + (uint64_t)frag * 3072, lane16);
+        vf[0] = vfbase[0]; vf[1] = vfbase[64]; vf[2] = vfbase[128];
+    };
+    {
+        const v4i vm = vmeta[yt0];  // (the first entry straight from memory: vm_lds is not visible before the first barrier)
+        v_ws = __builtin_amdgcn_readfirstlane(vm[0]); v_hi = __builtin_amdgcn_readfirstlane(vm[3]);
+        fetch_taps(__builtin_amdgcn_readfirstlane(vm[2]), yt0 * 16);
+    }
+    uint32_t zmask = 0;   // bit s: ring slot s holds an all-zero band
+    const uint32_t ring_bits = (uint32_t)((1ull << J.ring16) - 1ull);
+    for (int b = band0; b <= band_last; ++b) {
+        __syncthreads();  // every wave is done reading the previous band
+        {
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                if (cl + 4 * k < n16) *reinterpret_cast<v4i *>(lds_dst + 64 * k) = pre[k];
+            uint32_t seen = 0;  // alpha plane (wave 3): OR of (alpha ^ 0x80) bytes, zero iff every alpha is 0
+            const int k80 = (int)0x80808080u;
+            if (wave == 3) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k)
+                    if (cl + 4 * k < n16)
+                        seen |= (uint32_t)((pre[k][0] ^ k80) | (pre[k][1] ^ k80) | (pre[k][2] ^ k80) | (pre[k][3] ^ k80));
+            }
+            if (n16 > 8) {  // wide strips (shrinks below ~1/1.3): the rest of the band, not prefetched
+                const uint32_t o = band_off(b);
+                for (int k = 2; cl + 4 * k < n16; ++k) {
+                    const v4i v = *at<v4i>(gplane, o + 64u * k);
+                    *reinterpret_cast<v4i *>(lds_dst + 64 * k) = v;
+                    seen |= (uint32_t)((v[0] ^ k80) | (v[1] ^ k80) | (v[2] ^ k80) | (v[3] ^ k80));
+                }
+            }
+            if (wave == 3) {
+                const bool any = __any(seen != 0u);
+                if (lane == 0) band_alpha = any ? 1u : 0u;
+            }
+        }
+        __syncthreads();  // the band (and its alpha flag) is in LDS
+        if (b < band_last) prefetch(b + 1);
+        const bool zero_band = __builtin_amdgcn_readfirstlane((int)band_alpha) == 0;
+        const int slot = b & rmask;
+        if (active) {
+            uint8_t *m = m0 + 64 * slot;
+            if (zero_band) {
+                // premultiplied zeros in, clip8(2^21 >> 22) = 0 out: the intermediate rows are zero
+                zmask |= 1u << slot;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m + 16 * c) = 0x80808080u;
+            } else {
+                zmask &= ~(1u << slot);
+                // D[row = 4 lh + reg (band row)][col = l15 (x)]: 4 consecutive rows of one column
+                uint32_t w[4];
+                auto load = [&](int c) { return *reinterpret_cast<const v4i *>(a0 + c * plane_s); };
+                tile4<true>(load, hf, hbias, w);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<uint32_t *>(m + 16 * c) = w[c];
+            }
+        }
+        // ---- tiles of output rows whose last tap row is now in the ring (the next tile's table entry waits in
+        // scalar registers: a band that completes no tile costs one compare)
+        while (yt < n_yt && v_hi <= 16 * (b + 1)) {
+            // the table entry of the tile after this one (the last tile re-reads its own: always a valid fetch)
+            const int t_n = min(yt + 1, n_yt - 1);
+            const v4i vm_n = vm_lds[t_n];
+            const int n_ws = __builtin_amdgcn_readfirstlane(vm_n[0]), n_frag = __builtin_amdgcn_readfirstlane(vm_n[2]);
+            const int n_hi = __builtin_amdgcn_readfirstlane(vm_n[3]);
+            if (active) {
+                const int row0 = (yt0 + yt) * 16;  // first output row of the tile (scalar)
+                const bool inside = ox_ok && l15 < J.dh - row0;
+                const uint32_t o_idx = (uint32_t)(row0 * J.dw) + lane_idx;  // < 2^30 px
+                // every 16-row slot of the tile's window holds zeros? (window slots as a bit mask, rotated into the ring)
+                const int s_first = (v_ws >> 4) & rmask, n_slots = ((v_hi - 1) >> 4) - (v_ws >> 4) + 1;
+                // (64-bit: a ring of 32 slots makes these shifts reach 32 bits and beyond)
+                const uint64_t span = ((1ull << n_slots) - 1ull) << s_first;
+                const uint32_t need = (uint32_t)(span | (span >> J.ring16)) & ring_bits;
+                const bool all_zero = (zmask & need) == need;
+                u32x4 px = {0u, 0u, 0u, 0u};
+                if (!all_zero) {
+                    const int base16 = (v_ws >> 4) + lh;
+                    uint32_t w[4];
+                    // A[m = l15 (x)][k = 16 lh + j (window row)]; D[row = 4 lh + reg (x)][col = l15 (output row)]
+                    auto load = [&](int c) { return *reinterpret_cast<const v4i *>(r0 + ((base16 & rmask) << 6) + 16 * c); };
+                    tile4<false>(load, vf, v4i{vb, vb, vb, vb}, w);
+                    fetch_taps(n_frag, (yt0 + t_n) * 16);
+                    // alpha bytes all 0 or 255 <=> low 7 bits of every byte equal its top bit
+                    const uint32_t top = (w[3] >> 7) & 0x01010101u;
+                    const bool soft = (w[3] & 0x7F7F7F7Fu) != (top << 7) - top;
+                    px = __any(soft) ? unpremultiply4(w, recip) : interleave4(w);
+                } else {
+                    fetch_taps(n_frag, (yt0 + t_n) * 16);
+                }
+                if (x_full) {  // (wave-uniform) one 16-byte store per lane
+                    if (inside) *reinterpret_cast<MIC_GLOBAL u32x4_a4 *>(dst + o_idx) = px;
+                } else if (inside) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ox + j < J.dw) dst[o_idx + j] = px[j];
+                }
+            }
+            ++yt;
+            v_ws = n_ws; v_hi = n_hi;
+        }
+    }
 }
 
 hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, size_t lds_bytes, hipStream_t stream) {

@@ -52,7 +52,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *mic_last_error(void) { return g_err; }
-extern "C" int mic_version(void) { return (1 << 16) | 9; }  // 1.9: + mic_plan_invalidate, mic_layer_cache_clear, mic_stats.cached_layers / pipeline_groups (resident resampled layers, pipelined LANCZOS path); 1.8: + mic_png_write_async / mic_png_wait; 1.7: + mic_median_rgb_batch, mic_host_rows_solid, mic_download(_wait); 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
+extern "C" int mic_version(void) { return (1 << 16) | 9; }  // 1.9: + mic_plan_invalidate, mic_layer_cache_clear, mic_stats.cached_layers (resident resampled layers); 1.8: + mic_png_write_async / mic_png_wait; 1.7: + mic_median_rgb_batch, mic_host_rows_solid, mic_download(_wait); 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
 
 // ------------------------------------------------------------------------------------ blob layout
 namespace {
@@ -188,30 +188,6 @@ struct mic_ctx {
     int dl_next = 0;
     mic_stats stats{};
     uint64_t next_atlas_uid = 1;
-    // ---- the LANCZOS path as ONE path (round 4).  The resample kernel is bound by instruction issue and leaves wave
-    // slots idle over its ramp and tail, the composite kernel is bound by memory: they overlap well.  A call's resampled
-    // layers are cut into GROUPS in the order the composite needs them -- by canvas in multi-canvas calls, by canvas BAND
-    // (a run of 4 KiB pages) in single-canvas calls -- the groups' resample launches go to side streams, and the
-    // composite of a chunk of canvases / a band is enqueued on the caller's stream behind the event of the last group it
-    // reads: it runs while the next group is being resampled.  Outputs are complete once the caller's stream has drained
-    // (its last composite waits for the last group), as before.
-    static constexpr int kSideStreams = 3;
-    hipStream_t side[kSideStreams] = {};
-    std::vector<hipEvent_t> pipe_events;  // pool (timing disabled), reused call after call
-    // MEASURED (profiles/r04_pipeline_streams.txt): on this runtime a cross-stream dependency (event record on one HIP
-    // stream + hipStreamWaitEvent on another) costs 15-50 us of GPU idle time per edge -- more than the composite it would
-    // hide (C3 placements canvas: 73 us serial, 98-430 us with 2-12 bands; 16 canvases per call: 58.7 us per canvas
-    // serial, 63-107 us in chunks) -- whatever the event flags.  So both knobs default to the serial path; the groups
-    // below are what the FUSED launches (kernels_fused.hip) are cut by instead.
-    // FUSED launches (kernels_fused.hip): in a call over several canvases with opaque solid backgrounds, the marching
-    // resample of chunk k + 1 and the composite of chunk k are two roles of ONE launch on the caller's stream -- no
-    // events, no second stream.  MIC_FUSE_CHUNK: canvases per chunk (0 = off).
-    int fuse_chunk = 2;
-    int pipe_bands = 1;    // MIC_PIPE_BANDS: bands of a single-canvas call (<= 1: resample, then composite, on one stream)
-    int pipe_chunk = 0;    // MIC_PIPE_CHUNK: canvases per chunk of a multi-canvas call (<= 0: serial)
-    int pipe_streams = 1;  // MIC_PIPE_STREAMS: side streams the groups are dealt over (1: the groups run one after another)
-    bool pipe_prio = false;  // MIC_PIPE_PRIO=1: side streams created with descending priorities
-    unsigned pipe_evflags = hipEventDisableTiming;  // MIC_PIPE_EVFLAGS (hex): flags of the group events
     // ---- resampled layers stay resident (round 4): a transient call (mic_composite_batch, mic_render, mic_contact_sheet)
     // writes its resampled layers into this cache instead of the arena, keyed (atlas, cutout, box size, filter); a later
     // call that places the same cutout at the same size -- a refine iteration that moves a box without resizing it
@@ -294,12 +270,6 @@ extern "C" int mic_create(int device, mic_ctx **out) {
         }
     }
     if (const char *la = getenv("MIC_LAYER_ARGS")) ctx->layer_args = atoi(la) != 0;
-    if (const char *v = getenv("MIC_FUSE_CHUNK")) ctx->fuse_chunk = std::max(0, atoi(v));
-    if (const char *v = getenv("MIC_PIPE_BANDS")) ctx->pipe_bands = std::max(1, std::min(64, atoi(v)));
-    if (const char *v = getenv("MIC_PIPE_CHUNK")) ctx->pipe_chunk = std::max(0, atoi(v));
-    if (const char *v = getenv("MIC_PIPE_STREAMS")) ctx->pipe_streams = std::max(1, std::min((int)mic_ctx::kSideStreams, atoi(v)));
-    if (const char *v = getenv("MIC_PIPE_PRIO")) ctx->pipe_prio = atoi(v) != 0;
-    if (const char *v = getenv("MIC_PIPE_EVFLAGS")) ctx->pipe_evflags = (unsigned)strtoul(v, nullptr, 16);
     if (const char *v = getenv("MIC_LAYER_CACHE_MB")) ctx->layer_cache_cap = (size_t)std::max(0ll, atoll(v)) << 20;
     if (const char *tl = getenv("MIC_MEDIAN_TWO_LAUNCHES")) ctx->median_two_launches = atoi(tl) != 0 ? 1 : 0;
     e = hipMalloc(&ctx->median_scratch, (kMedianScratchWords + 64) * sizeof(uint32_t));
@@ -331,9 +301,6 @@ extern "C" int mic_destroy(mic_ctx *ctx) {
     for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->dl_event)
         if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : ctx->pipe_events) (void)hipEventDestroy(ev);
-    for (hipStream_t st : ctx->side)
-        if (st) (void)hipStreamDestroy(st);
     for (auto &r : ctx->layer_regions)
         if (r.dev) (void)hipFree(r.dev);
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -685,9 +652,6 @@ struct ResizePlan {
     uint64_t planar_src = 0;  // the cutout in its atlas' planar premultiplied copy (0: none)
     int planar_pitch = 0;
     int atlas = -1, entry = -1;  // where the source is a cutout of an atlas
-    // where the composite first needs the layer: the first job that places it, and the top-most canvas row of its
-    // boxes in that job (the pipelined path resamples in that order)
-    int first_job = 0, first_row = 0;
     bool cached = false;  // the pixels are in the context's resident layer cache already (dst_ptr): no pass is emitted
 };
 
@@ -701,11 +665,6 @@ struct PassTables {
     size_t lds_march = 0;
     std::vector<RsJob> h, v;
     int max_h_out_w = 0, max_h_rows = 0, max_v_out_w = 0, max_v_out_h = 0;
-    // The marching entries are emitted in the order the composite needs their layers: by first job, then by first
-    // canvas row.  marks[k] = that key of the k-th marching layer and the number of entries up to and including it,
-    // so "everything jobs <= j / rows <= y need" is a prefix of `fused`.
-    struct Mark { int job, row, fused_end; };
-    std::vector<Mark> marks;
 };
 
 // Over all groups of `per` consecutive 16-sample tiles along one axis: the largest window extent a
@@ -824,16 +783,8 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
     for (const ResizePlan &p : plans)
         if (p.march) march_px += (int64_t)p.dw * p.dh;
     const int64_t unit_px = march_unit_px(march_px);
-    std::vector<size_t> order;  // marching layers first, in need order; then the others in plan order
-    for (size_t i = 0; i < plans.size(); ++i)
-        if (plans[i].march && !plans[i].cached) order.push_back(i);
-    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
-        return std::make_pair(plans[a].first_job, plans[a].first_row) < std::make_pair(plans[b].first_job, plans[b].first_row);
-    });
-    for (size_t i = 0; i < plans.size(); ++i)
-        if (!plans[i].march && !plans[i].cached) order.push_back(i);
-    for (const size_t pi : order) {
-        const ResizePlan &p = plans[pi];
+    for (const ResizePlan &p : plans) {
+        if (p.cached) continue;  // the pixels are in the resident layer cache: no pass
         const bool need_h = p.dw != p.sw, need_v = p.dh != p.sh;
         const uint64_t dst = p.dst_ptr ? p.dst_ptr : arena + p.dst_off;
         if (p.march) {
@@ -857,7 +808,6 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             f.xcd_rot = pt->fused_layers++ & 7;  // the XCD that gets a layer's short last run rotates
             for (f.entry = 0; f.entry < f.n_entries; ++f.entry) pt->fused.push_back(f);
             pt->lds_march = std::max(pt->lds_march, rs_march_lds_bytes(f.pitch_c, f.pitch_r));
-            pt->marks.push_back({p.first_job, p.first_row, (int)pt->fused.size()});
             continue;
         }
         if (p.tx16 > 0) {
@@ -957,7 +907,7 @@ struct mic_plan {
         int class_end[3] = {0, 0, 0};
         int pitch = 0;
         uint64_t last_use = 0;
-        std::vector<int> order_idx;  // position in the (class-sorted) device table -> caller's job index
+
     };
     static constexpr int kJobTables = 4;
     JobTable job_tables[kJobTables];
@@ -966,8 +916,6 @@ struct mic_plan {
     // of the (immutable) atlases, so a later run finds them there and only composites -- a refine iteration, a batch
     // re-rendered onto other canvases.  mic_plan_invalidate() makes the next run resample again (bench.py's cold legs).
     bool resampled_valid = false;
-    std::vector<int> order_idx;  // ordered[k] is the caller's job order_idx[k] (this run)
-    int pipeline_groups = 1;     // resample groups of the last run (stats)
 };
 
 static void plan_offsets(mic_plan *P) {
@@ -1144,15 +1092,11 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                 size_t plan_idx;
                 if (dit != dedup.end()) {
                     plan_idx = dit->second;
-                    if (plans[plan_idx].first_job == ji)
-                        plans[plan_idx].first_row = std::min(plans[plan_idx].first_row, (int)std::max<int64_t>(0, y1));
                 } else {
                     ResizePlan rp{};
                     rp.src = reinterpret_cast<uint64_t>(A->blob) + E.offset;
                     rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
                     rp.atlas = Pl.atlas; rp.entry = it->second;
-                    rp.first_job = ji;
-                    rp.first_row = (int)std::max<int64_t>(0, y1);
                     if (int rc = choose_march(ctx, &rp, filter)) return rc;
                     if (int rc = choose_tile(ctx, &rp, filter)) return rc;
                     plan_idx = plans.size();
@@ -1352,16 +1296,8 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
             key.resize((size_t)n_jobs);
             for (int ji = 0; ji < n_jobs; ++ji) key[(size_t)ji] = P->ordered[(size_t)ji].out;
         }
-        {
-            std::vector<int> idx((size_t)n_jobs);
-            for (int ji = 0; ji < n_jobs; ++ji) idx[(size_t)ji] = ji;
-            const std::vector<Job> &src = P->ordered;
-            std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return job_class(src[(size_t)a]) < job_class(src[(size_t)b]); });
-            std::vector<Job> sorted((size_t)n_jobs);
-            for (int k = 0; k < n_jobs; ++k) sorted[(size_t)k] = src[(size_t)idx[(size_t)k]];
-            P->ordered.swap(sorted);
-            P->order_idx.swap(idx);
-        }
+        std::stable_sort(P->ordered.begin(), P->ordered.end(),
+                         [&](const Job &a, const Job &b) { return job_class(a) < job_class(b); });
         for (const Job &d : P->ordered)
             for (int c = job_class(d); c < 3; ++c) ++class_end[c];
 
@@ -1401,10 +1337,8 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
             slot_tab->outs = std::move(key);
             memcpy(slot_tab->class_end, class_end, sizeof class_end);
             slot_tab->pitch = pitch;
-            slot_tab->order_idx = P->order_idx;
         }
     }
-    const std::vector<int> &order_idx = cached ? slot_tab->order_idx : P->order_idx;
     const Job *jobs_dev = one ? nullptr : (P->persistent ? slot_tab->dev : reinterpret_cast<const Job *>(dp));
 
     for (const auto &todo : P->planar_todo) {
@@ -1420,8 +1354,8 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     const RsMarch *fused_dev = reinterpret_cast<const RsMarch *>(dp + P->off_f);
     // a persistent plan that has run before finds its resampled layers in its own scratch: composite only
     const bool resident = P->persistent && P->resampled_valid;
-    P->pipeline_groups = 1;
     if (!resident) {
+        HIP_TRY(launch_resample_march(fused_dev, (int)P->pt.fused.size(), P->pt.lds_march, stream));
         HIP_TRY(launch_resample_tile(reinterpret_cast<const RsTile *>(dp + P->off_t), (int)P->pt.tiles.size(),
                                       P->pt.tiles_whole, P->pt.tiles_lds, stream));
         HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + P->off_h), (int)P->pt.h.size(),
@@ -1429,142 +1363,19 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + P->off_v), (int)P->pt.v.size(),
                                   P->pt.max_v_out_w, P->pt.max_v_out_h, stream));
     }
-    // ---- groups of the pipelined path (see mic_ctx): {marching entries [fb, fe), the part of the composite that may
-    // follow them: sorted jobs [a, b), or pages [a, b) of the only job}
-    struct Group { int fb, fe, a, b; };
-    std::vector<Group> groups;
-    const int n_fused = resident ? 0 : (int)P->pt.fused.size();
-    const std::vector<PassTables::Mark> &marks = P->pt.marks;
-    // fused launches take canvases over an opaque solid background (kernel classes 0 and 1: every job of the table
-    // when class_end[1] == n_jobs); anything else may still be pipelined over side streams (off by default)
-    const bool fuse = !one && ctx->fuse_chunk > 0 && class_end[1] == n_jobs;
-    const int chunk = fuse ? ctx->fuse_chunk : ctx->pipe_chunk;
-    if (n_fused > 0 && marks.size() > 1) {
-        if (one && ctx->pipe_bands > 1) {
-            const Job &d = P->ordered[0];
-            const int64_t n_px = (int64_t)d.W * d.H;
-            const int bands = std::min(ctx->pipe_bands, std::max(1, d.n_pages / 64));  // >= 64 pages (256 KiB) per band
-            int done = 0;
-            for (int k = 0; k < bands; ++k) {
-                const int p0 = (int)((int64_t)d.n_pages * k / bands) / 8 * 8;
-                const int p1 = k + 1 == bands ? d.n_pages : (int)((int64_t)d.n_pages * (k + 1) / bands) / 8 * 8;
-                if (p1 <= p0) continue;
-                // the last canvas row the band's pages touch; every layer whose first row is <= that may be read
-                const int64_t q_last = std::min<int64_t>(n_px - 1, (int64_t)p1 * kPagePx - d.px_shift - 1);
-                const int row_last = (int)(q_last / d.W);
-                auto it = std::upper_bound(marks.begin(), marks.end(), row_last,
-                                           [](int row, const PassTables::Mark &m) { return row < m.row; });
-                const int fe = k + 1 == bands ? n_fused : std::max(done, it == marks.begin() ? 0 : (it - 1)->fused_end);
-                groups.push_back({done, fe, p0, p1});
-                done = fe;
-            }
-        } else if (!one && chunk > 0 && n_jobs > chunk) {
-            // chunks of `chunk` canvases in table order; the last chunk is cut in halves (.., 2, 1, 1) so that the
-            // composite nothing is left to hide is a small one
-            std::vector<int> cuts;
-            int at = 0;
-            while (n_jobs - at > chunk) { at += chunk; cuts.push_back(at); }
-            for (int rest = n_jobs - at; rest > 1; rest -= rest / 2) { at += rest / 2; cuts.push_back(at); }
-            cuts.push_back(n_jobs);
-            int a = 0, done = 0, need_job = -1;
-            for (int b : cuts) {
-                for (int k = a; k < b; ++k) need_job = std::max(need_job, order_idx[(size_t)k]);
-                auto it = std::upper_bound(marks.begin(), marks.end(), need_job,
-                                           [](int job, const PassTables::Mark &m) { return job < m.job; });
-                const int fe = b == n_jobs ? n_fused : std::max(done, it == marks.begin() ? 0 : (it - 1)->fused_end);
-                groups.push_back({done, fe, a, b});
-                done = fe;
-                a = b;
-            }
-        }
-        int with_work = 0;
-        for (const Group &g : groups) with_work += g.fe > g.fb;
-        if (with_work < 2) groups.clear();  // nothing to overlap: the serial path
-    }
-    if (groups.empty()) {
-        HIP_TRY(launch_resample_march(fused_dev, n_fused, P->pt.lds_march, stream));
-        if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
-        HIP_TRY(launch_composite(jobs_dev, layers_dev, n_jobs, class_end, pitch, one ? &P->ordered[0] : nullptr,
-                                 pack_layers ? P->layers.data() : nullptr, stream));
-    } else if (fuse) {
-        // resample(g0) | fused{resample(g1), composite(part 0)} | ... | composite(last part): one stream, no events
-        P->pipeline_groups = (int)groups.size();
-        const bool all_aligned = class_end[0] == n_jobs;
-        auto composite_part = [&](const Group &G) -> int {
-            int ce[3];
-            for (int c = 0; c < 3; ++c) ce[c] = std::min(std::max(class_end[c], G.a), G.b) - G.a;
-            HIP_TRY(launch_composite(jobs_dev + G.a, layers_dev, G.b - G.a, ce, pitch, nullptr, nullptr, stream));
-            return MIC_OK;
-        };
-        HIP_TRY(launch_resample_march(fused_dev + groups[0].fb, groups[0].fe - groups[0].fb, P->pt.lds_march, stream));
-        for (size_t g = 1; g < groups.size(); ++g) {
-            const Group &R = groups[g], &C = groups[g - 1];
-            if (R.fe > R.fb) {
-                HIP_TRY(launch_fused(fused_dev + R.fb, R.fe - R.fb, P->pt.lds_march, jobs_dev + C.a, layers_dev, C.b - C.a, pitch,
-                                     all_aligned, stream));
-            } else if (int rc = composite_part(C)) {
-                return rc;
-            }
-        }
-        if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
-        if (int rc = composite_part(groups.back())) return rc;
-    } else {
-        P->pipeline_groups = (int)groups.size();
-        const int n_side = std::min(ctx->pipe_streams, (int)mic_ctx::kSideStreams);
-        for (int k = 0; k < n_side; ++k)
-            if (!ctx->side[k]) {
-                int lo = 0, hi = 0;
-                if (ctx->pipe_prio) HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));  // (hi: the numerically lowest = greatest priority)
-                HIP_TRY(hipStreamCreateWithPriority(&ctx->side[k], hipStreamNonBlocking, ctx->pipe_prio ? std::min(lo, hi + k) : 0));
-            }
-        // events: one that orders the side streams behind everything the caller's stream holds (table uploads, planar
-        // copies, the previous call's composites reading the same scratch), one per group
-        auto event_at = [&](size_t i, hipEvent_t *ev) -> int {
-            while (ctx->pipe_events.size() <= i) {
-                hipEvent_t e;
-                HIP_TRY(hipEventCreateWithFlags(&e, ctx->pipe_evflags));
-                ctx->pipe_events.push_back(e);
-            }
-            *ev = ctx->pipe_events[i];
-            return MIC_OK;
-        };
-        hipEvent_t ev_start;
-        if (int rc = event_at(0, &ev_start)) return rc;
-        HIP_TRY(hipEventRecord(ev_start, stream));
-        for (int k = 0; k < n_side; ++k) HIP_TRY(hipStreamWaitEvent(ctx->side[k], ev_start, 0));
-        std::vector<hipEvent_t> gev(groups.size(), nullptr);
-        int dealt = 0;
-        for (size_t g = 0; g < groups.size(); ++g) {
-            const Group &G = groups[g];
-            if (G.fe <= G.fb) continue;
-            hipStream_t st = ctx->side[dealt++ % n_side];
-            HIP_TRY(launch_resample_march(fused_dev + G.fb, G.fe - G.fb, P->pt.lds_march, st));
-            if (int rc = event_at(1 + g, &gev[g])) return rc;
-            HIP_TRY(hipEventRecord(gev[g], st));
-        }
-        for (size_t g = 0; g < groups.size(); ++g) {
-            const Group &G = groups[g];
-            if (gev[g]) HIP_TRY(hipStreamWaitEvent(stream, gev[g], 0));
-            if (prof && g + 1 == groups.size()) HIP_TRY(hipEventRecord(pe[1], stream));
-            if (one) {
-                Job band = P->ordered[0];
-                band.page_begin = G.a;
-                band.n_pages = G.b;
-                HIP_TRY(launch_composite(nullptr, layers_dev, 1, class_end, (G.b - G.a + 7) / 8 * 8, &band,
-                                         pack_layers ? P->layers.data() : nullptr, stream));
-            } else {
-                int ce[3];
-                for (int c = 0; c < 3; ++c) ce[c] = std::min(std::max(class_end[c], G.a), G.b) - G.a;
-                HIP_TRY(launch_composite(jobs_dev + G.a, layers_dev, G.b - G.a, ce, pitch, nullptr, nullptr, stream));
-            }
-        }
-    }
+    if (prof) HIP_TRY(hipEventRecord(pe[1], stream));
+    // (Overlapping the issue-bound resample with the memory-bound composite was built twice in round 4 -- resample groups
+    // on side streams with the composite of a canvas band / a chunk of canvases behind each group's event, and FUSED
+    // launches with the two kernels as roles of one -- bit-exact both, slower both: a cross-stream edge costs 15-50 us on
+    // this runtime, and the composite starves inside the resample kernel's register / LDS budget.
+    // profiles/r04_pipeline_streams.txt, r04_fused_launches.txt, r04_overlap_experiments.patch.)
+    HIP_TRY(launch_composite(jobs_dev, layers_dev, n_jobs, class_end, pitch, one ? &P->ordered[0] : nullptr,
+                             pack_layers ? P->layers.data() : nullptr, stream));
     if (prof) {
         HIP_TRY(hipEventRecord(pe[2], stream));
         ++ctx->prof_calls;
     }
     if (P->persistent) P->resampled_valid = true;
-    P->stats.pipeline_groups = (uint64_t)P->pipeline_groups;
     P->stats.composite_blocks = (uint64_t)pitch * n_jobs;
     ctx->stats = P->stats;
     return MIC_OK;

@@ -44,8 +44,8 @@ struct alignas(16) Job {
     int32_t W, H;
     int32_t layer_begin, layer_count;
     int32_t px_shift;  // pixels of the canvas' first 4 KiB page that precede the canvas: (out % 4096) / 4
-    int32_t n_pages;   // ceil((W*H + px_shift) / 1024); a band launch: one past the band's last page
-    int32_t page_begin;  // first page this launch covers (a multiple of 8; 0 except in the band launches of the pipelined LANCZOS path)
+    int32_t n_pages;   // ceil((W*H + px_shift) / 1024)
+    int32_t pad0;
 };
 static_assert(sizeof(Job) == 48, "Job layout");
 
@@ -160,9 +160,6 @@ struct alignas(16) PlanarJob {
 static_assert(sizeof(PlanarJob) == 32, "PlanarJob layout");
 hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream);
 hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, size_t lds_bytes, hipStream_t stream);
-// kernels_fused.hip: ONE launch = the marching resample of the next chunk of canvases + the composite of the previous one
-hipError_t launch_fused(const RsMarch *rs_jobs_dev, int n_rs, size_t lds_bytes, const Job *jobs_dev, const Layer *layers_dev,
-                        int n_jobs, int pitch, bool all_aligned, hipStream_t stream);
 hipError_t launch_resample_tile(const RsTile *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes, hipStream_t stream);
 // Known-answer canary of the clip / pack / (un)premultiply helpers (kernels_resample.hip): 0 mismatches expected.
 hipError_t run_selftest_clip(hipStream_t stream, int *mismatches, int *first_bad);

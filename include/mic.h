@@ -298,7 +298,6 @@ typedef struct mic_stats {
     uint64_t composite_blocks;    /* workgroups launched by the composite kernel           */
     uint64_t marched_layers;      /* of resampled_layers: those run by the marching resample kernel (1.5) */
     uint64_t cached_layers;       /* of the call's distinct resampled layers: found in the resident cache (1.9) */
-    uint64_t pipeline_groups;     /* resample groups the call's launches were cut into; 1 = resample, then composite (1.9) */
 } mic_stats;
 int mic_last_stats(const mic_ctx *ctx, mic_stats *out);
 int mic_plan_stats(const mic_plan *plan, mic_stats *out);
@@ -306,11 +305,7 @@ int mic_plan_stats(const mic_plan *plan, mic_stats *out);
 /* Kernel timing with HIP events recorded on the launch stream, for bench.py's roofline: between
  * mic_profile_begin and mic_profile_end every mic_composite_batch call brackets its composite
  * kernel (and, separately, its resample passes) with an event pair.  mic_profile_end waits for
- * the stream, then reports the number of bracketed calls and the summed durations in ms.
- * A call that runs the pipelined LANCZOS path (mic_stats.pipeline_groups > 1: resample groups on side
- * streams, the composite of a band / a chunk of canvases behind each) reports as resample_ms the span
- * up to the start of its LAST composite launch (earlier composites ran inside it) and as composite_ms
- * that last launch: the sum is the call's whole GPU time on the stream either way.                */
+ * the stream, then reports the number of bracketed calls and the summed durations in ms.       */
 int mic_profile_begin(mic_ctx *ctx, int max_calls);
 /* Same, bracketing only every `every`-th call (an event pair between two back-to-back kernels costs
  * a few microseconds of idle GPU; sampling keeps the timed loop representative).                 */
