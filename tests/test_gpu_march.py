@@ -28,11 +28,13 @@ def forced():
     from image_transformation_amd import _native
     lib = _native.lib()
     os.environ["MIC_RS_MARCH_MIN_UNITS"] = "0"
+    os.environ["MIC_LAYER_CACHE_MB"] = "0"  # every call resamples (a resident layer of an earlier call would skip the kernel under test)
     try:
         ctx = P()
         assert lib.mic_create(torch.cuda.current_device(), ctypes.byref(ctx)) == 0, lib.mic_last_error()
     finally:
         del os.environ["MIC_RS_MARCH_MIN_UNITS"]
+        del os.environ["MIC_LAYER_CACHE_MB"]
     yield lib, ctx, _native
     assert lib.mic_destroy(ctx) == 0
 
