@@ -37,7 +37,7 @@ class Job(ctypes.Structure):
     _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32),
                 ("bg_dev", ctypes.c_void_p), ("bg_rgba", ctypes.c_uint8 * 4),
                 ("n_placements", ctypes.c_int32), ("placements", ctypes.POINTER(Placement)),
-                ("out_dev", ctypes.c_void_p)]
+                ("out_dev", ctypes.c_void_p), ("bg_rgba_dev", ctypes.c_void_p)]
 
 
 class LabelStrip(ctypes.Structure):
@@ -105,6 +105,7 @@ SYMBOLS = {
                                       ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _I32P, _I32P, _I32P]),
     "mic_render": (ctypes.c_int, [_P, _P, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, _P,
                                   ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, _P, _P, _I32P]),
+    "mic_render_job": (ctypes.c_int, [_P, _P, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(Job), ctypes.c_int, _P, _I32P]),
     "mic_thumbnail_size": (ctypes.c_int, [ctypes.c_int32] * 4 + [_I32P, _I32P]),
     "mic_contact_sheet_size": (ctypes.c_int, [ctypes.c_int32] * 5 + [_I32P, _I32P]),
     "mic_contact_sheet": (ctypes.c_int, [_P, _P, ctypes.c_int32, _I32P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

@@ -553,16 +553,44 @@ def _fill_placements(rows: Sequence[Tuple[int, int, int, int, int]], atlas_index
 
 class SolidCanvas:
     """A canvas that is one colour: what fill_solid() produces (background_resizing.py:25-33).
-    Passing it to render() lets the kernel synthesise the background instead of reading it."""
+    Passing it to render() lets the kernel synthesise the background instead of reading it.
 
-    def __init__(self, size: Tuple[int, int], rgba: Sequence[int]):
+    The colour is either known on the host (`rgba`) or lives in device memory (`colour_dev`: a 4-byte uint8 tensor
+    r, g, b, a that a kernel enqueued earlier on the stream writes -- the median kernel's result, solid_canvas()): the
+    composite reads it when it runs, so background synthesis -> render never waits for the GPU.  Reading `.rgba` of
+    such a canvas downloads the colour (one stream wait), once."""
+
+    def __init__(self, size: Tuple[int, int], rgba: Optional[Sequence[int]] = None, *, colour_dev=None):
         self.size = (int(size[0]), int(size[1]))
-        rgba = tuple(int(v) for v in rgba)
-        if len(rgba) == 3:
-            rgba = rgba + (255,)
-        if len(rgba) != 4 or any(not 0 <= v <= 255 for v in rgba):
-            raise ValueError("colour must be 3 or 4 values in 0..255")
-        self.rgba = rgba
+        self.colour_dev = colour_dev
+        self._rgba = None
+        if rgba is not None:
+            rgba = tuple(int(v) for v in rgba)
+            if len(rgba) == 3:
+                rgba = rgba + (255,)
+            if len(rgba) != 4 or any(not 0 <= v <= 255 for v in rgba):
+                raise ValueError("colour must be 3 or 4 values in 0..255")
+            self._rgba = rgba
+        elif colour_dev is None:
+            raise ValueError("a SolidCanvas needs a colour: rgba, or colour_dev (4 bytes on the device)")
+        elif colour_dev.numel() != 4 or colour_dev.element_size() != 1 or not colour_dev.is_contiguous():
+            raise ValueError("colour_dev must be 4 contiguous bytes r, g, b, a on the device")
+
+    @property
+    def rgba(self) -> Tuple[int, int, int, int]:
+        if self._rgba is None:
+            self._rgba = tuple(int(v) for v in self.colour_dev.cpu().tolist())  # (waits for the kernel that writes it)
+        return self._rgba
+
+    def _job_colour(self, job) -> None:
+        """Fill a ctypes Job's background fields."""
+        job.bg_dev = None
+        if self._rgba is not None or self.colour_dev is None:
+            r, c = self.rgba, job.bg_rgba
+            c[0], c[1], c[2], c[3] = r[0], r[1], r[2], r[3]
+            job.bg_rgba_dev = None
+        else:
+            job.bg_rgba_dev = self.colour_dev.data_ptr()
 
     def to_image(self) -> Image.Image:
         return Image.new("RGBA", self.size, self.rgba)
@@ -571,9 +599,12 @@ class SolidCanvas:
 def _make_job(size, bg_dev_ptr, bg_rgba, placement_arr, n_place, out_ptr) -> Job:
     j = Job()
     j.width, j.height = size
-    j.bg_dev = bg_dev_ptr
-    for k in range(4):
-        j.bg_rgba[k] = bg_rgba[k]
+    if isinstance(bg_rgba, SolidCanvas):
+        bg_rgba._job_colour(j)
+    else:
+        j.bg_dev = bg_dev_ptr
+        for k in range(4):
+            j.bg_rgba[k] = bg_rgba[k]
     j.n_placements = n_place
     j.placements = ctypes.cast(placement_arr, ctypes.POINTER(Placement))
     j.out_dev = out_ptr
@@ -591,7 +622,8 @@ def _build_jobs(atlas: "Atlas", canvases, placement_rows, atlas_of: Optional[Seq
     for i, (cv, rows) in enumerate(zip(canvases, placement_rows)):
         if isinstance(cv, SolidCanvas):
             W, H = cv.size
-            bg_ptr, rgba = None, cv.rgba
+            bg_ptr, rgba = None, cv  # (the colour, host or device, is filled in by the canvas itself)
+            keep.append(cv)
         else:
             if cv.dtype != torch.uint8 or cv.dim() != 3 or cv.shape[2] != 4 or not cv.is_contiguous():
                 raise ValueError("device canvas must be a contiguous uint8 (H, W, 4) tensor")
@@ -807,10 +839,8 @@ def _composite_one(atlas: Atlas, canvas, rows, filter: int, download: bool = Tru
     keep = None
     if isinstance(canvas, SolidCanvas):
         W, H = canvas.size
-        j.bg_dev = None
-        r = canvas.rgba
-        c = j.bg_rgba
-        c[0], c[1], c[2], c[3] = r[0], r[1], r[2], r[3]
+        canvas._job_colour(j)
+        keep = canvas
     else:
         if canvas.dtype != torch.uint8 or canvas.dim() != 3 or canvas.shape[2] != 4 or not canvas.is_contiguous():
             raise ValueError("device canvas must be a contiguous uint8 (H, W, 4) tensor")
@@ -818,6 +848,7 @@ def _composite_one(atlas: Atlas, canvas, rows, filter: int, download: bool = Tru
             raise ValueError("canvas lives on another device than the atlas")
         H, W = int(canvas.shape[0]), int(canvas.shape[1])
         j.bg_dev = canvas.data_ptr()
+        j.bg_rgba_dev = None
         keep = canvas
     j.width, j.height, j.n_placements = W, H, n
     nbytes = H * W * 4
@@ -942,19 +973,24 @@ def _render_native(layout_json: Any, atlas: "Atlas", canvas: Any, size: Tuple[in
     torch = _torch()
     ctx = atlas.ctx
     W, H = size
+    job = _tls.__dict__.get("render_job")
+    if job is None:
+        job = _tls.render_job = Job()
+    job.width, job.height, job.n_placements = W, H, 0
     if isinstance(canvas, SolidCanvas):
-        bg_ptr, rgba = None, (ctypes.c_uint8 * 4)(*canvas.rgba)
+        canvas._job_colour(job)
     else:
         if canvas.dtype != torch.uint8 or canvas.dim() != 3 or canvas.shape[2] != 4 or not canvas.is_contiguous():
             raise ValueError("device canvas must be a contiguous uint8 (H, W, 4) tensor")
         if canvas.device != ctx.torch_device:
             raise ValueError("canvas lives on another device than the atlas")
-        bg_ptr, rgba = canvas.data_ptr(), (ctypes.c_uint8 * 4)(0, 0, 0, 0)
+        job.bg_dev, job.bg_rgba_dev = canvas.data_ptr(), None
     out = torch.empty((H, W, 4), dtype=torch.uint8, device=ctx.torch_device)
+    job.out_dev = out.data_ptr()
     atlas.wait_ready()
     with _device_guard(ctx):
-        rc = _native.lib().mic_render(ctx.handle, atlas.handle, text, len(text), W, H, _P(bg_ptr) if bg_ptr else None,
-                                      rgba, filter, _P(out.data_ptr()), _P(ctx.stream_ptr()), None)
+        rc = _native.lib().mic_render_job(ctx.handle, atlas.handle, text, len(text), ctypes.byref(job), filter,
+                                          _P(ctx.stream_ptr()), None)
     if rc in (_native.ERR_UNSUPPORTED, _native.ERR_FORMAT):
         return None
     _native.check(rc)

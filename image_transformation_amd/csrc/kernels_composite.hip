@@ -218,8 +218,17 @@ struct LayerPack {
 template <bool ALIGNED, bool SOLID, int MODE>
 __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6 : 4)) void composite_kernel(
     const Job *__restrict__ jobs, const Layer *__restrict__ layers, const Job one, const LayerPack pack) {
-    const Job job = MODE != kFromTables ? one : jobs[blockIdx.y];
+    Job job = MODE != kFromTables ? one : jobs[blockIdx.y];
     if ((int)blockIdx.x >= job.n_pages) return;
+    // A solid colour that lives in device memory (mic_job.bg_rgba_dev: the median kernel's result, consumed without a
+    // host round trip): one scalar load, in flight while the layer records are fetched.  The host classes such a job
+    // as SOLID (opaque); a colour word that turns out not to be opaque sends the page through the exact per-pixel path
+    // just before the store (below).
+    const bool colour_word = (job.flags & kJobColourWord) != 0;  // wave-uniform
+    if (colour_word) {
+        job.bg_rgba = *reinterpret_cast<const MIC_GLOBAL uint32_t *>(job.bg);
+        job.bg = 0;
+    }
     const int lane = threadIdx.x;
     const int W = job.W;
     const int64_t n_px = (int64_t)job.W * job.H;
@@ -445,6 +454,10 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
         }
     }
 
+    if (SOLID && colour_word && (job.bg_rgba >> 24) != 255u) {  // (wave-uniform, never taken by fill_solid's colours)
+        edge_page(job, jl, qp, lane);
+        return;
+    }
     // ---- the canvas is written exactly once: four coalesced 1 KiB stores per page ----
     gptr out = reinterpret_cast<gptr>(job.out) + q_lane;
 #pragma unroll

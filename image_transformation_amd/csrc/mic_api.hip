@@ -1051,6 +1051,12 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
         d.bg = reinterpret_cast<uint64_t>(J.bg_dev);
         d.bg_rgba = (uint32_t)J.bg_rgba[0] | ((uint32_t)J.bg_rgba[1] << 8) | ((uint32_t)J.bg_rgba[2] << 16) |
                     ((uint32_t)J.bg_rgba[3] << 24);
+        if (J.bg_rgba_dev) {  // the solid colour is a word in device memory (mic_median_rgb_dev's result)
+            if (J.bg_dev) return fail(MIC_ERR_INVALID, "job %d: both a background image and a device colour word", ji);
+            d.bg = reinterpret_cast<uint64_t>(J.bg_rgba_dev);
+            d.bg_rgba = 0xff000000u;  // (never read by the kernels; the class below says opaque solid)
+            d.flags = kJobColourWord;
+        }
         d.W = J.width;
         d.H = J.height;
         d.layer_begin = (int32_t)P->layers.size();
@@ -1264,7 +1270,8 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
             const uint64_t bytes = (uint64_t)d.W * d.H * 4;
             // compositor.py:11 copies the background: a canvas that overlaps it anywhere would be read
             // by one wave after another wave has written it
-            if (d.bg && d.out < d.bg + bytes && d.bg < d.out + bytes)
+            const uint64_t bg_bytes = (d.flags & kJobColourWord) ? 4 : bytes;
+            if (d.bg && d.out < d.bg + bg_bytes && d.bg < d.out + bytes)
                 return fail(MIC_ERR_INVALID, "job %d: output overlaps the background", ji);
             if (d.out % 4 != 0) return fail(MIC_ERR_INVALID, "job %d: canvas pointers must be 4-byte aligned", ji);
             // 4 KiB pages aligned to absolute address: one workgroup per page (see mic_internal.h)
@@ -1288,7 +1295,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         // background (the pipeline's own canvases), 1 = unaligned + solid, 2 = aligned + other, 3 = rest
         auto job_class = [](const Job &d) {
             const bool aligned = d.W % 4 == 0 && d.out % 16 == 0;
-            const bool solid = d.bg == 0 && (d.bg_rgba >> 24) == 255u;
+            const bool solid = (d.bg == 0 && (d.bg_rgba >> 24) == 255u) || (d.flags & kJobColourWord);
             return (solid ? 0 : 2) + (aligned ? 0 : 1);
         };
         std::vector<uint64_t> key;
@@ -1410,8 +1417,21 @@ extern "C" int mic_plan_invalidate(mic_plan *plan) {
 extern "C" int mic_render(mic_ctx *ctx, mic_atlas *atlas, const char *layout_json, size_t len, int32_t width,
                           int32_t height, const void *bg_dev, const uint8_t bg_rgba[4], int filter, void *out_dev,
                           void *stream_v, int32_t *n_placed) {
+    if (!bg_dev && !bg_rgba) return fail(MIC_ERR_INVALID, "mic_render: bad arguments");
+    mic_job canvas{};
+    canvas.width = width; canvas.height = height;
+    canvas.bg_dev = bg_dev;
+    if (bg_rgba) memcpy(canvas.bg_rgba, bg_rgba, 4);
+    canvas.out_dev = out_dev;
+    return mic_render_job(ctx, atlas, layout_json, len, &canvas, filter, stream_v, n_placed);
+}
+
+extern "C" int mic_render_job(mic_ctx *ctx, mic_atlas *atlas, const char *layout_json, size_t len, const mic_job *canvas,
+                              int filter, void *stream_v, int32_t *n_placed) {
     CTX_ENTER(ctx);
-    if (!atlas || !layout_json || !out_dev || width <= 0 || height <= 0 || (!bg_dev && !bg_rgba))
+    if (!canvas) return fail(MIC_ERR_INVALID, "mic_render: bad arguments");
+    const int32_t width = canvas->width, height = canvas->height;
+    if (!atlas || !layout_json || !canvas->out_dev || width <= 0 || height <= 0)
         return fail(MIC_ERR_INVALID, "mic_render: bad arguments");
     if (atlas->ctx != ctx) return fail(MIC_ERR_INVALID, "mic_render: atlas belongs to another context");
     // the sizes the placer sees: one entry per id, the first occurrence (what a dict would hold)
@@ -1437,13 +1457,9 @@ extern "C" int mic_render(mic_ctx *ctx, mic_atlas *atlas, const char *layout_jso
         pl[i].object_id = oi[i];
         for (int k = 0; k < 4; ++k) pl[i].box[k] = ob[4 * i + k];
     }
-    mic_job job{};
-    job.width = width; job.height = height;
-    job.bg_dev = bg_dev;
-    if (bg_rgba) memcpy(job.bg_rgba, bg_rgba, 4);
+    mic_job job = *canvas;
     job.n_placements = (int32_t)pl.size();
     job.placements = pl.data();
-    job.out_dev = out_dev;
     mic_atlas *atl[1] = {atlas};
     return mic_composite_batch(ctx, 1, atl, 1, &job, filter, stream_v);
 }

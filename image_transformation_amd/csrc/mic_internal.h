@@ -39,14 +39,15 @@ static_assert(sizeof(Layer) == 32, "Layer layout");
 // One canvas.
 struct alignas(16) Job {
     uint64_t out;      // device address of the W*H canvas
-    uint64_t bg;       // device address of a W*H background image, 0 = solid colour
+    uint64_t bg;       // device address of a W*H background image, 0 = solid colour; flags & kJobColourWord: of ONE colour word
     uint32_t bg_rgba;  // solid colour, little-endian r | g<<8 | b<<16 | a<<24
     int32_t W, H;
     int32_t layer_begin, layer_count;
     int32_t px_shift;  // pixels of the canvas' first 4 KiB page that precede the canvas: (out % 4096) / 4
     int32_t n_pages;   // ceil((W*H + px_shift) / 1024)
-    int32_t pad0;
+    int32_t flags;     // kJobColourWord: the solid colour is read from device memory at `bg` (mic_job.bg_rgba_dev)
 };
+constexpr int32_t kJobColourWord = 1;
 static_assert(sizeof(Job) == 48, "Job layout");
 
 // ---- resample ------------------------------------------------------------------------------

@@ -199,7 +199,8 @@ def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, ori
         writer.text(d0["vlm_input_text"] / "run_metadata.json", meta)
         writer.save(sheet, d0["vlm_input_image"] / "contact_sheet.png")
         writer.copy(bg_path, d0["vlm_input_image"] / "background.png")
-        writer.save(canvas.to_image(), d0["vlm_input_image"] / "canvas.png")
+        # (canvas.png needs the colour on the host: written after the loop, when the median kernel has long finished --
+        # asking for it here would be the run's only wait for the GPU before the first draft)
 
     drafts: List[Image.Image] = []
     all_placements: List[List[Dict]] = []
@@ -223,5 +224,7 @@ def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, ori
                         d["final_product"] / f"overlay_debug_iter_{i:02d}.png")  # :1514, :1700
             writer.text(d["layout_json"] / f"provenance_iter_{i:02d}.json", {"method": "flex", "fallback": False, "iteration": i})
         steps.add("compose_baseline" if i == 0 else f"compose_iter_{i:02d}", t0)  # (:1492, :1678)
+    if save:
+        writer.save(canvas.to_image(), made[0]["vlm_input_image"] / "canvas.png")  # :1428-1430
     return {"canvas_size": canvas_size, "background_rgba": canvas.rgba, "contact_sheet": sheet, "drafts": drafts,
             "placements": all_placements, "output_dir": str(base_out) if base_out else None}

@@ -127,6 +127,12 @@ typedef struct mic_job {
     const mic_placement *placements; /* host array                                        */
     void *out_dev;                   /* device RGBA canvas, width*height*4 bytes; must not
                                         alias bg_dev (compositor.py:11 copies the bg)      */
+    const void *bg_rgba_dev;         /* (1.9) NULL, or the solid colour as 4 bytes r,g,b,a in DEVICE memory, read by
+                                        the kernel when it runs -- e.g. what mic_median_rgb_dev wrote earlier on the
+                                        same stream: fill_solid()'s colour (background_resizing.py:25-33) reaches the
+                                        composite that consumes it without a host round trip.  bg_dev must be NULL
+                                        and bg_rgba is ignored then.  Opaque colours (a = 255, what mic_median_rgb_dev
+                                        writes) take the fast kernels; any other alpha is composited exactly, slowly. */
 } mic_job;
 
 int mic_composite_batch(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,
@@ -281,6 +287,10 @@ int mic_flex_place(const char *layout_json, size_t len, int n_objects, const int
 int mic_render(mic_ctx *ctx, mic_atlas *atlas, const char *layout_json, size_t len, int32_t width,
                int32_t height, const void *bg_dev, const uint8_t bg_rgba[4], int filter, void *out_dev,
                void *stream, int32_t *n_placed);
+/* (1.9) The same with the canvas described by a mic_job: width, height, bg_dev / bg_rgba / bg_rgba_dev and out_dev are
+ * taken from *canvas, its placement fields are ignored (the Flex tree provides the placements).                   */
+int mic_render_job(mic_ctx *ctx, mic_atlas *atlas, const char *layout_json, size_t len, const mic_job *canvas,
+                   int filter, void *stream, int32_t *n_placed);
 
 /* ---- helpers ----------------------------------------------------------------------------- */
 /* Pillow Image.thumbnail size rule (macro_placement_test.py:194). */

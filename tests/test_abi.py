@@ -44,19 +44,19 @@ def test_struct_layouts_match_header(tmp_path):
     src = tmp_path / "sizes.c"
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mic.h"\n'
                    'int main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(mic_placement), offsetof(mic_placement, box), '
-                   'sizeof(mic_job), offsetof(mic_job, out_dev), sizeof(mic_stats), offsetof(mic_stats, marched_layers), '
+                   'sizeof(mic_job), offsetof(mic_job, bg_rgba_dev), sizeof(mic_stats), offsetof(mic_stats, cached_layers), '
                    'sizeof(mic_label_strip), offsetof(mic_label_strip, coverage_host), '
                    'sizeof(mic_image_view), offsetof(mic_image_view, stride_bytes)); return 0; }\n')
     exe = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), "-o", str(exe), str(src)])
     got = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     mine = [ctypes.sizeof(_native.Placement), _native.Placement.box.offset,
-            ctypes.sizeof(_native.Job), _native.Job.out_dev.offset,
-            ctypes.sizeof(_native.Stats), _native.Stats.marched_layers.offset,
+            ctypes.sizeof(_native.Job), _native.Job.bg_rgba_dev.offset,
+            ctypes.sizeof(_native.Stats), _native.Stats.cached_layers.offset,
             ctypes.sizeof(_native.LabelStrip), _native.LabelStrip.coverage_host.offset,
             ctypes.sizeof(_native.ImageView), _native.ImageView.stride_bytes.offset]
     assert got == mine, (got, mine)
-    assert got[0] == 24 and got[2] == 40 and got[4] == 72  # mic_stats: 9 counters since ABI 1.9
+    assert got[0] == 24 and got[2] == 48 and got[4] == 72  # ABI 1.9: mic_job.bg_rgba_dev, mic_stats.cached_layers
 
 
 def test_binding_refuses_another_abi_version(built_lib, monkeypatch):

@@ -799,3 +799,75 @@ def test_large_pil_backgrounds(gpu):
             assert np.array_equal(np.array(composite(_img(bg), pil_objs, pl)), want), (W, H, rep)
             if rep == 0:
                 assert np.array_equal(render({"placements": pl}, pil_objs, _img(bg), as_tensor=True).cpu().numpy(), want)
+
+
+def test_solid_canvas_with_a_device_colour_word(gpu):
+    """Round 4: a SolidCanvas whose colour lives in device memory (mic_job.bg_rgba_dev: what the median kernel wrote on the
+    stream) composites like the same colour given on the host -- single-canvas launches (job in the kernel arguments),
+    batches (job table), render() through mic_render_job, aligned / unaligned widths, LANCZOS layers; a colour word that
+    is NOT opaque takes the exact per-pixel path; the colour is only downloaded when `.rgba` is read."""
+    import torch
+    from image_transformation_amd import _native
+    from image_transformation_amd.background_resizing import median_color_device
+    from image_transformation_amd.compositor import (Atlas, CompositeBatch, SolidCanvas, composite_device, coerce_placements,
+                                                     render)
+    rng = np.random.default_rng(808)
+    objs = {i + 1: cases.synthetic.make_cutout(rng, int(rng.integers(30, 120)), int(rng.integers(20, 90)), "soft") for i in range(5)}
+    atlas = Atlas(objs)
+    for colour in ((38, 73, 115, 255), (200, 10, 60, 130), (0, 0, 0, 0)):
+        word = torch.tensor(colour, dtype=torch.uint8, device=gpu.torch_device)
+        sizes = [(333, 97), (256, 64), (1030, 41), (64, 64)]
+        pls, cvs_dev, cvs_host, bgs = [], [], [], []
+        for (W, H) in sizes:
+            pl = []
+            for _ in range(int(rng.integers(1, 9))):
+                oid = int(rng.integers(1, 6))
+                sh, sw = objs[oid].shape[:2]
+                if rng.random() < 0.4:
+                    sw, sh = max(1, int(sw * rng.uniform(0.5, 1.7))), max(1, int(sh * rng.uniform(0.5, 1.7)))
+                x1, y1 = int(rng.integers(-sw // 2, W)), int(rng.integers(-sh // 2, H))
+                pl.append({"object_id": oid, "box": [x1, y1, x1 + sw, y1 + sh]})
+            pls.append(pl)
+            cvs_dev.append(SolidCanvas((W, H), colour_dev=word))
+            cvs_host.append(SolidCanvas((W, H), colour))
+            bg = np.empty((H, W, 4), np.uint8)
+            bg[:] = colour
+            bgs.append(bg)
+        rows = [coerce_placements(atlas, pl) for pl in pls]
+        wants = [oracle.composite(bgs[i], objs, pls[i]) for i in range(len(sizes))]
+        for cvs in (cvs_dev, cvs_host):
+            for i, o in enumerate(composite_device(atlas, cvs, rows)):            # one launch, job table
+                assert np.array_equal(o.cpu().numpy(), wants[i]), (colour, i)
+            for i in range(len(sizes)):                                             # one canvas per call, job in the arguments
+                got = composite_device(atlas, [cvs[i]], [rows[i]])[0].cpu().numpy()
+                assert np.array_equal(got, wants[i]), (colour, "single", i)
+            plan = CompositeBatch(atlas, cvs, rows)
+            for rep in range(2):
+                for i, o in enumerate(plan.run()):
+                    assert np.array_equal(o.cpu().numpy(), wants[i]), (colour, "plan", rep, i)
+        assert cvs_dev[0]._rgba is None  # nothing above asked for the colour on the host ...
+        assert cvs_dev[0].rgba == colour and cvs_dev[0].to_image().getpixel((0, 0)) == colour  # ... this does
+    # render() through mic_render_job, colour straight from the median kernel (no host round trip in between)
+    W, H = 640, 360
+    img = rng.integers(0, 256, (70, 90, 4), dtype=np.uint8)
+    dev = torch.from_numpy(img).to(gpu.torch_device)
+    word = torch.empty(4, dtype=torch.uint8, device=gpu.torch_device)
+    _native.check(_native.lib().mic_median_rgb_dev(gpu.handle, ctypes.c_void_p(dev.data_ptr()), 90, 70,
+                                                   ctypes.c_void_p(word.data_ptr()), ctypes.c_void_p(gpu.stream_ptr())))
+    layout = {"root": {"type": "flex", "direction": "row", "justify": "space_around", "align": "center", "gap_px": 5,
+                       "children": [{"object_id": k} for k in objs]}}
+    got = render(layout, atlas, SolidCanvas((W, H), colour_dev=word), as_tensor=True).cpu().numpy()
+    med = oracle.median_rgb(img)
+    assert median_color_device(dev) == med
+    bg = np.empty((H, W, 4), np.uint8)
+    bg[:] = med + (255,)
+    from image_transformation_amd import flex
+    assert np.array_equal(got, oracle.composite(bg, objs, flex.layout_to_placements(layout, atlas, (W, H))))
+    # a background image AND a colour word: refused
+    lib = _native.lib()
+    job = _native.Job()
+    out = torch.empty((8, 8, 4), dtype=torch.uint8, device=gpu.torch_device)
+    job.width, job.height, job.out_dev, job.bg_dev, job.bg_rgba_dev = 8, 8, out.data_ptr(), dev.data_ptr(), word.data_ptr()
+    atl = (ctypes.c_void_p * 1)(atlas.handle)
+    assert lib.mic_composite_batch(gpu.handle, 1, atl, 1, ctypes.byref(job), 0, ctypes.c_void_p(gpu.stream_ptr())) < 0
+    assert b"both a background image and a device colour word" in lib.mic_last_error()
