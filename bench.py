@@ -418,7 +418,87 @@ def c4_strong_leg(D: Dist, args, steps, warmup):
     }, atlas
 
 
+def cold_start_child():
+    """Runs in a FRESH child process (bench.py --cold-start-child): what the reference's caller sees the first time --
+    import, context + code object, the first load_object_images / contact sheet / fill_solid / composite on the
+    squarespace bundle (macro_placement_test.py:1397-1511) -- stage by stage, each stage's SECOND call beside it, then the
+    same sequence through Pillow / NumPy in the same process.  Prints one JSON object."""
+    t_start = time.perf_counter()
+    out = {}
+
+    def stage(name, fn):
+        t0 = time.perf_counter()
+        r = fn()
+        out[name] = round((time.perf_counter() - t0) * 1e3, 3)
+        return r
+    import numpy as np  # noqa: F401
+    t0 = time.perf_counter()
+    import torch
+    out["import_torch_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    t0 = time.perf_counter()
+    from image_transformation_amd import _native, flex
+    from image_transformation_amd.background_resizing import fill_solid
+    from image_transformation_amd.compositor import composite, load_object_images
+    from image_transformation_amd.contact_sheet import build_labeled_contact_sheet
+    out["import_package_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    bdir = os.path.join(ROOT, "tests", "golden", "bundles", "squarespace")
+    rj, bgp = os.path.join(bdir, "results.json"), os.path.join(bdir, "background.png")
+    with open(os.path.join(ROOT, "tests", "golden", "bundles.json"), encoding="utf-8") as f:
+        layout = next(r for r in json.load(f)["cases"] if r["name"] == "squarespace_1x1")["layout"]
+    size = (492, 492)
+    stage("context_and_code_object_ms", lambda: (_native.context(), torch.cuda.synchronize()))
+    for tag in ("first", "second"):
+        objs = stage(f"load_object_images_{tag}_ms", lambda: load_object_images(rj))
+        stage(f"contact_sheet_{tag}_ms", lambda: build_labeled_contact_sheet(os.path.join(bdir, "objects"), rj))
+        bg = stage(f"fill_solid_{tag}_ms", lambda: fill_solid(bgp, size))
+        pl = flex.layout_to_placements(layout, objs, size)
+        stage(f"composite_{tag}_ms", lambda: composite(bg, objs, pl))
+    out["total_first_pass_ms"] = round(sum(v for k, v in out.items() if k.endswith("_first_ms")) + out["context_and_code_object_ms"], 3)
+    # the same sequence through Pillow / NumPy (the files are in the page cache by now, Pillow is imported)
+    from PIL import Image
+    pil = {}
+
+    def pstage(name, fn):
+        t0 = time.perf_counter()
+        r = fn()
+        pil[name] = round((time.perf_counter() - t0) * 1e3, 3)
+        return r
+    for tag in ("first", "second"):
+        def load():
+            with open(rj, encoding="utf-8") as f:
+                return {int(it["object_id"]): Image.open(os.path.join(bdir, it["filename"])).convert("RGBA") for it in json.load(f)}
+        pobjs = pstage(f"load_object_images_{tag}_ms", load)
+        pstage(f"contact_sheet_{tag}_ms", lambda: _pillow_contact_sheet(rj))
+        pbg = pstage(f"fill_solid_{tag}_ms", lambda: Image.new("RGBA", size, _numpy_median_colour(Image.open(bgp).convert("RGBA")) + (255,)))
+        ppl = flex.layout_to_placements(layout, pobjs, size)
+        pstage(f"composite_{tag}_ms", lambda: _pillow_composite(pbg, pobjs, ppl))
+    pil["total_first_pass_ms"] = round(sum(v for k, v in pil.items() if k.endswith("_first_ms")), 3)
+    out["pillow_numpy"] = pil
+    out["process_wall_ms"] = round((time.perf_counter() - t_start) * 1e3, 1)
+    print(json.dumps(out), flush=True)
+
+
+def cold_start():
+    """Spawn the child (a subprocess, not an exec of this process) and return its record."""
+    import subprocess
+
+    try:
+        res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cold-start-child"], capture_output=True, text=True,
+                             timeout=300, cwd=ROOT)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        if res.returncode != 0 or not line:
+            return {"error": (res.stderr or res.stdout)[-400:]}
+        rec = json.loads(line[-1])
+        rec["what"] = ("a fresh process on the squarespace bundle (492x492, 4 cutouts): first call of every stage of the "
+                       "reference's sequence, the second call beside it, Pillow / NumPy's same sequence in the same process")
+        return rec
+    except Exception as exc:  # noqa: BLE001
+        return {"error": repr(exc)}
+
+
 def main():
+    if "--cold-start-child" in sys.argv:
+        return cold_start_child()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -625,6 +705,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_extras:
         extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_sets, n_sets, size, dev)
+        result["cold_start"] = cold_start()
 
     if dist_on:
         D.barrier()
@@ -759,10 +840,9 @@ def pipeline_extras(result, ctx, dev):
         # cache (cleared here), iterations 1-3 move the boxes without resizing them and find the x8 upscales resident
         if it == 0:
             _native.check(_native.lib().mic_layer_cache_clear(ctx.handle))
-        one()
         sync()
         t0 = time.perf_counter()
-        one()  # (second call of the iteration: code paths and allocator warm, cache state as the loop leaves it)
+        one()  # ONE call in loop order: iteration 0 resamples, 1-3 find the layers
         t_seq = time.perf_counter() - t0
         hits = ctx.stats()["cached_layers"]
         t_wall, _ = _median_time(one, 0.5, 50)
@@ -782,7 +862,8 @@ def pipeline_extras(result, ctx, dev):
         t0 = time.perf_counter()
         _pillow_composite(bg8k, pil_objs, pl)
         t_cpu = time.perf_counter() - t0
-        iters.append({"iteration": it, "render_to_device_wall_ms": round(t_wall * 1e3, 3), "cached_layers_in_the_loop": hits,
+        iters.append({"iteration": it, "render_to_device_wall_ms": round(t_wall * 1e3, 3),
+                      "render_to_device_wall_ms_in_loop_order": round(t_seq * 1e3, 3), "cached_layers_in_loop_order": hits,
                       "composite_kernel_ms_layers_resident": round(c_warm, 4), "resample_kernel_ms": round(r_ms, 4),
                       "composite_kernel_ms": round(c_ms, 4), "composite_algorithmic_bytes": plan_bytes(st),
                       "composite_roofline_frac": frac(plan_bytes(st), c_ms), "resample_algorithmic_bytes": rs_bytes,
@@ -828,12 +909,16 @@ def pipeline_extras(result, ctx, dev):
         p_mine, p_pil = os.path.join(td, "d_mine.png"), os.path.join(td, "d_pil.png")
         t_png, _ = _median_time(lambda: mic_png.save(draft4k, p_mine), 2.0, 50)
         t_png_pil, _ = _median_time(lambda: draft4k.save(p_pil), 3.0, 5)
+        # what a 4K caller of draft.save waits for in all: render (enqueue + kernel + 33 MB download) + encode + write
+        canvas4k = SolidCanvas((3840, 2160), (38, 73, 115, 255))
+        t_render_save, _ = _median_time(lambda: mic_png.save(render(l4[0], o4, canvas4k), p_mine), 2.0, 50)
         sizes = (os.path.getsize(p_mine), os.path.getsize(p_pil))
     result["run_layouts"] = {
         "what": "squarespace bundle, ratio 1:1 (492x492), 3 iterations: contact sheet + fill_solid + 3 x (place, clamp, composite)",
         "ms_without_saving": round(t_nosave * 1e3, 3), "ms_with_png_artifacts": round(t_save * 1e3, 3),
         "pillow_ms_without_saving": round(t_cpu_nosave * 1e3, 3), "pillow_ms_with_png_artifacts": round(t_cpu_save * 1e3, 3),
         "png_4k_draft": {"libmic_writer_ms": round(t_png * 1e3, 2), "pil_save_ms": round(t_png_pil * 1e3, 1),
+                         "render_to_saved_png_wall_ms": round(t_render_save * 1e3, 2),
                          "bytes_libmic": sizes[0], "bytes_pil": sizes[1]},
         "note": "the Pillow figures restate the reference's sequence (cutouts decoded every iteration, canvas.png written and "
                 "re-opened) in this file; this package's artifacts: contact sheet, canvas, 3 drafts, 3 overlays, JSONs"}
@@ -1084,6 +1169,14 @@ def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_
                 t_mine, _ = _median_time(lambda: composite(c1_bg, c1_objs, q), 1.0, 5000)
                 t_pil, _ = _median_time(lambda: _pillow_composite(c1_bg, c1_pil, q), 1.0, 300)
                 c1[key] = {"this_package_us": round(t_mine * 1e6, 1), "pillow_us": round(t_pil * 1e6, 1)}
+                if key != "identity_scale":
+                    # the number above finds the four resampled cutouts resident (the same boxes call after call); this
+                    # one forgets them before every call: resample + composite each time
+                    def _cold_call():
+                        _native.check(_native.lib().mic_layer_cache_clear(c1_objs.atlas().ctx.handle))
+                        composite(c1_bg, c1_objs, q)
+                    t_cold, _ = _median_time(_cold_call, 1.0, 5000)
+                    c1[key]["this_package_us_layers_not_resident"] = round(t_cold * 1e6, 1)
             # where the identity-scale call's time goes (stages timed on their own; profiles/r03_c1_breakdown.json has more)
             from image_transformation_amd import _pilmem as _pm
             from image_transformation_amd import compositor as _C

@@ -114,6 +114,11 @@ SYMBOLS = {
                                            ctypes.POINTER(ctypes.c_int)]),
     "mic_download": (ctypes.c_int, [_P, _P, _P, ctypes.c_size_t, _P, _I32P]),
     "mic_download_wait": (ctypes.c_int, [_P, ctypes.c_int32]),
+    "mic_png_info": (ctypes.c_int, [_P, ctypes.c_size_t, _I32P, _I32P]),
+    "mic_png_decode": (ctypes.c_int, [_P, ctypes.c_size_t, _P, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32]),
+    "mic_png_decode_rows": (ctypes.c_int, [_P, ctypes.c_size_t, _P, ctypes.c_int32, ctypes.c_int32]),
+    "mic_png_decode_many": (ctypes.c_int, [ctypes.c_int32, _P, _P, _P, _I32P, _I32P, ctypes.c_int, _I32P]),
+    "mic_png_decode_counts": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     "mic_png_bound": (ctypes.c_size_t, [ctypes.c_int32, ctypes.c_int32]),
     "mic_png_encode": (ctypes.c_int, [_P, ctypes.c_int32, ctypes.c_int32, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _P,
                                       ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]),

@@ -51,6 +51,17 @@ def _workers() -> concurrent.futures.ThreadPoolExecutor:
 
 
 _good_layout: Optional[int] = None  # index into _LAYOUTS that row_runs() has validated in this process
+# Which path the callers of this module took, per process: "zero_copy" = Pillow's rows were reached in place,
+# "fallback" = the image's memory could not be located (an unknown struct layout, a lazy image) and the caller went
+# through np.asarray / Image.tobytes instead -- correct, but ~14 ms per 4K image.  path_report() names the layout.
+counters = {"zero_copy": 0, "fallback": 0}
+_LAYOUT_NAMES = ("Pillow >= 12 (mode kept as an enum)", "Pillow < 12 (mode kept as char[7])")
+
+
+def path_report() -> dict:
+    """{"layout": which ImagingMemoryInstance layout was validated in this process (None: none yet / none fits),
+    "zero_copy": calls that reached Pillow's rows in place, "fallback": calls that had to copy through Pillow}."""
+    return {"layout": None if _good_layout is None else _LAYOUT_NAMES[_good_layout], **counters}
 
 
 def row_table(img: Image.Image) -> Optional[Tuple[int, int, int]]:
@@ -76,8 +87,13 @@ def row_table(img: Image.Image) -> Optional[Tuple[int, int, int]]:
         if (head[o_bands >> 2], head[o_x >> 2], head[o_y >> 2], head[o_px >> 2], head[o_line >> 2]) != (4, W, H, 4, 4 * W):
             return None
         table = ctypes.c_uint64.from_address(base + o_image).value
-        return (table, W, H) if table else None
+        if table:
+            counters["zero_copy"] += 1
+            return table, W, H
+        counters["fallback"] += 1
+        return None
     except Exception:
+        counters["fallback"] += 1
         return None
 
 
@@ -113,13 +129,16 @@ def row_runs(img: Image.Image) -> Optional[List[Tuple[int, int]]]:
             if first != tuple(img.getpixel((0, 0))) or last != tuple(img.getpixel((W - 1, H - 1))):
                 continue
             _good_layout = li
+            counters["zero_copy"] += 1
             line = 4 * W
             brk = np.nonzero(np.diff(rows) != line)[0] + 1
             starts = np.concatenate([[0], brk])
             ends = np.concatenate([brk, [H]])
             return [(int(rows[s]), int(e - s) * line) for s, e in zip(starts, ends)]
+        counters["fallback"] += 1
         return None
     except Exception:
+        counters["fallback"] += 1
         return None
 
 

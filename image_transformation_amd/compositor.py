@@ -47,22 +47,56 @@ class _DecodeCache:
     _lock = threading.Lock()  # the reference's Streamlit app runs every session on its own thread
     LIMIT = 512 << 20
 
+    @staticmethod
+    def _decode_files(paths: Sequence[str]) -> List[Image.Image]:
+        """Image.open(p).convert("RGBA") for every path: libmic's PNG reader (csrc/png_decode.cpp, several files at a
+        time on its own threads, straight into the images' memory) for the kinds of PNG it takes; any file it declines --
+        another format, 16-bit, interlaced, anything irregular -- goes to Pillow, which decodes it or raises."""
+        from . import png as mic_png
+        blobs = []
+        for p in paths:
+            with open(p, "rb") as f:  # FileNotFoundError like Image.open
+                blobs.append(f.read())
+        ims = mic_png.decode_many(blobs)
+        for i, im in enumerate(ims):
+            if im is None:
+                ims[i] = Image.open(paths[i]).convert("RGBA")
+        return ims
+
+    @classmethod
+    def _fetch(cls, paths: Sequence[Any]) -> List[Image.Image]:
+        """The cached decodes of `paths` (decoding the missing ones together)."""
+        keys = []
+        for path in paths:
+            p = os.fspath(path)
+            st = os.stat(p)  # raises FileNotFoundError like Image.open
+            keys.append((os.path.abspath(p), st.st_mtime_ns, st.st_size))
+        with cls._lock:
+            ims = [cls._items.get(k) for k in keys]
+        missing = [i for i, im in enumerate(ims) if im is None]
+        if missing:
+            fresh = cls._decode_files([keys[i][0] for i in missing])
+            with cls._lock:
+                for i, im in zip(missing, fresh):
+                    nbytes = im.size[0] * im.size[1] * 4
+                    if cls._bytes + nbytes > cls.LIMIT:
+                        cls._items.clear()
+                        cls._bytes = 0
+                    cls._items[keys[i]] = im
+                    cls._bytes += nbytes
+                    ims[i] = im
+        return ims
+
+    @classmethod
+    def open_many(cls, paths: Sequence[Any], shared: bool = False) -> List[Image.Image]:
+        return [cls._hand_out(im, shared) for im in cls._fetch(paths)]
+
     @classmethod
     def open_rgba(cls, path, shared: bool = False) -> Image.Image:
-        p = os.fspath(path)
-        st = os.stat(p)  # raises FileNotFoundError like Image.open
-        key = (os.path.abspath(p), st.st_mtime_ns, st.st_size)
-        with cls._lock:
-            im = cls._items.get(key)
-        if im is None:
-            im = Image.open(p).convert("RGBA")
-            nbytes = im.size[0] * im.size[1] * 4
-            with cls._lock:
-                if cls._bytes + nbytes > cls.LIMIT:
-                    cls._items.clear()
-                    cls._bytes = 0
-                cls._items[key] = im
-                cls._bytes += nbytes
+        return cls._hand_out(cls._fetch([path])[0], shared)
+
+    @staticmethod
+    def _hand_out(im: Image.Image, shared: bool) -> Image.Image:
         if shared:
             # a second Python object over the SAME pixel memory, flagged read-only: Pillow's in-place operations
             # (putpixel, paste, alpha_composite, ImageDraw, putalpha ...) copy the pixels before they write, so the
@@ -505,9 +539,10 @@ def load_object_images(results_json_path: str, shared: bool = False) -> Dict[int
     base = os.path.dirname(results_json_path)
     out = ObjectImages()
     keys = []
-    for it in items:
-        path = os.path.join(base, it["filename"])
-        out[int(it["object_id"])] = open_rgba(path, shared)
+    paths = [os.path.join(base, it["filename"]) for it in items]
+    images = _DecodeCache.open_many(paths, shared)  # (files not seen before are decoded together)
+    for it, path, im in zip(items, paths, images):
+        out[int(it["object_id"])] = im
         st = os.stat(path)
         keys.append((int(it["object_id"]), os.path.abspath(path), st.st_mtime_ns, st.st_size))
     out._source_key = tuple(keys)  # (after the inserts above, which reset it)

@@ -10,6 +10,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <climits>
 #include <cstdarg>
@@ -27,6 +28,7 @@
 #include "../../include/mic.h"  // declares mic_plan, mic_ctx, mic_atlas
 #include "mic_internal.h"
 #include "flex_place.h"
+#include "png_decode.h"
 #include "png_encode.h"
 #include "resample_coeffs.h"
 
@@ -52,7 +54,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *mic_last_error(void) { return g_err; }
-extern "C" int mic_version(void) { return (1 << 16) | 9; }  // 1.9: + mic_plan_invalidate, mic_layer_cache_clear, mic_stats.cached_layers (resident resampled layers); 1.8: + mic_png_write_async / mic_png_wait; 1.7: + mic_median_rgb_batch, mic_host_rows_solid, mic_download(_wait); 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
+extern "C" int mic_version(void) { return (1 << 16) | 9; }  // 1.9: + mic_plan_invalidate, mic_layer_cache_clear, mic_stats.cached_layers (resident resampled layers), mic_job.bg_rgba_dev, mic_render_job, mic_png_info / _decode(_rows, _many, _counts); 1.8: + mic_png_write_async / mic_png_wait; 1.7: + mic_median_rgb_batch, mic_host_rows_solid, mic_download(_wait); 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
 
 // ------------------------------------------------------------------------------------ blob layout
 namespace {
@@ -1974,6 +1976,75 @@ extern "C" int mic_png_write_rows(const char *path, const void *const *rows_host
     mic::PngPieces pieces;
     if (int rc = png_pieces(rows_host, nullptr, width, height, 0, level, threads, &pieces)) return rc;
     return png_to_file(pieces, path);
+}
+
+// ------------------------------------------------------------------------------------ PNG reader (host only)
+static std::atomic<uint64_t> g_png_decoded{0}, g_png_declined{0};
+
+static int png_status(int rc, const std::string &err) {
+    if (rc == 0) {
+        g_png_decoded.fetch_add(1, std::memory_order_relaxed);
+        return MIC_OK;
+    }
+    g_png_declined.fetch_add(1, std::memory_order_relaxed);
+    return fail(rc == mic::kPngUnsupported ? MIC_ERR_UNSUPPORTED : rc == mic::kPngNoMem ? MIC_ERR_NOMEM : MIC_ERR_FORMAT, "%s", err.c_str());
+}
+
+extern "C" int mic_png_info(const void *png, size_t bytes, int32_t *width, int32_t *height) {
+    if (!png || !width || !height) return fail(MIC_ERR_INVALID, "mic_png_info: null argument");
+    std::string err;
+    const int rc = mic::png_decode_info(static_cast<const uint8_t *>(png), bytes, width, height, &err);
+    if (rc == 0) return MIC_OK;
+    return fail(rc == mic::kPngUnsupported ? MIC_ERR_UNSUPPORTED : MIC_ERR_FORMAT, "%s", err.c_str());
+}
+
+extern "C" int mic_png_decode_rows(const void *png, size_t bytes, void *const *rows_host, int32_t width, int32_t height) {
+    if (!png || !rows_host || width <= 0 || height <= 0) return fail(MIC_ERR_INVALID, "mic_png_decode: bad arguments");
+    for (int32_t y = 0; y < height; ++y)
+        if (!rows_host[y]) return fail(MIC_ERR_INVALID, "mic_png_decode: row %d is null", y);
+    std::string err;
+    const int rc = mic::png_decode_rows(static_cast<const uint8_t *>(png), bytes, reinterpret_cast<uint8_t *const *>(rows_host), width,
+                                        height, true, &err);
+    return png_status(rc, err);
+}
+
+extern "C" int mic_png_decode(const void *png, size_t bytes, void *rgba_out, size_t stride_bytes, int32_t width, int32_t height) {
+    if (!png || !rgba_out || width <= 0 || height <= 0 || stride_bytes < (size_t)width * 4)
+        return fail(MIC_ERR_INVALID, "mic_png_decode: bad arguments");
+    std::vector<void *> rows((size_t)height);
+    for (int32_t y = 0; y < height; ++y) rows[(size_t)y] = static_cast<uint8_t *>(rgba_out) + (size_t)y * stride_bytes;
+    return mic_png_decode_rows(png, bytes, rows.data(), width, height);
+}
+
+extern "C" int mic_png_decode_many(int32_t n, const void *const *pngs, const size_t *bytes, void *const *const *rows_host,
+                                   const int32_t *widths, const int32_t *heights, int threads, int32_t *status) {
+    if (n < 0 || (n > 0 && (!pngs || !bytes || !rows_host || !widths || !heights || !status)))
+        return fail(MIC_ERR_INVALID, "mic_png_decode_many: bad arguments");
+    for (int32_t i = 0; i < n; ++i) {
+        if (!pngs[i] || !rows_host[i] || widths[i] <= 0 || heights[i] <= 0) return fail(MIC_ERR_INVALID, "mic_png_decode_many: file %d: bad arguments", i);
+        for (int32_t y = 0; y < heights[i]; ++y)
+            if (!rows_host[i][y]) return fail(MIC_ERR_INVALID, "mic_png_decode_many: file %d: row %d is null", i, y);
+    }
+    std::string err;
+    std::vector<int> st((size_t)std::max(n, 1), 0);
+    const int rc = mic::png_decode_many(n, reinterpret_cast<const uint8_t *const *>(pngs), bytes,
+                                        reinterpret_cast<uint8_t *const *const *>(rows_host), widths, heights, threads, st.data(), &err);
+    uint64_t ok = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        ok += st[(size_t)i] == 0;
+        status[i] = st[(size_t)i] == 0 ? MIC_OK : st[(size_t)i] == mic::kPngUnsupported ? MIC_ERR_UNSUPPORTED
+                                         : st[(size_t)i] == mic::kPngNoMem ? MIC_ERR_NOMEM : MIC_ERR_FORMAT;
+    }
+    g_png_decoded.fetch_add(ok, std::memory_order_relaxed);
+    g_png_declined.fetch_add((uint64_t)n - ok, std::memory_order_relaxed);
+    if (rc == 0) return MIC_OK;
+    return fail(rc == mic::kPngUnsupported ? MIC_ERR_UNSUPPORTED : rc == mic::kPngNoMem ? MIC_ERR_NOMEM : MIC_ERR_FORMAT, "%s", err.c_str());
+}
+
+extern "C" int mic_png_decode_counts(uint64_t *decoded, uint64_t *declined) {
+    if (decoded) *decoded = g_png_decoded.load(std::memory_order_relaxed);
+    if (declined) *declined = g_png_declined.load(std::memory_order_relaxed);
+    return MIC_OK;
 }
 
 extern "C" int mic_flex_place(const char *layout_json, size_t len, int n_objects, const int32_t *ids,

@@ -132,6 +132,78 @@ def encode(image, level: int = DEFAULT_LEVEL, threads: int = 0) -> bytes:
     return buf[:n.value].tobytes()
 
 
+# ------------------------------------------------------------------------------------------ reading
+_DECODE_OFF = os.environ.get("MIC_PNG_DECODE") == "0"  # MIC_PNG_DECODE=0: every file goes to Pillow (A/B, debugging)
+
+
+def _new_rgba(w: int, h: int):
+    """An uninitialised RGBA PIL image of its own + the address of Pillow's row-pointer table for it (or None)."""
+    im = Image.new("RGBA", (w, h), None)
+    tab = _pilmem.row_table(im)
+    return im, (tab[0] if tab is not None else None)
+
+
+def decode_many(blobs, threads: int = 0):
+    """PNG files in memory -> RGBA PIL images, decoded by libmic (csrc/png_decode.cpp) straight into the images' own
+    memory, several files at a time on the library's threads.  An entry is None where the decoder DECLINES the file
+    (16-bit, interlaced, a colour key, anything irregular): the caller hands that one to Pillow, which decodes it or
+    raises its own error.  Equals Image.open(f).convert("RGBA") byte for byte (tests/test_png_decode.py)."""
+    n = len(blobs)
+    out = [None] * n
+    if n == 0 or _DECODE_OFF:
+        return out
+    lib = _native.lib()
+    w, h = ctypes.c_int32(), ctypes.c_int32()
+    todo, ims, tables = [], [], []
+    for i, b in enumerate(blobs):
+        if lib.mic_png_info(b, len(b), ctypes.byref(w), ctypes.byref(h)) != 0:
+            continue
+        im, table = _new_rgba(w.value, h.value)
+        if table is None:  # Pillow's memory cannot be located: decode into an array, then wrap it
+            arr = np.empty((h.value, w.value, 4), np.uint8)
+            if lib.mic_png_decode(b, len(b), _P(arr.ctypes.data), 4 * w.value, w.value, h.value) == 0:
+                out[i] = Image.fromarray(arr, "RGBA")
+            continue
+        todo.append(i)
+        ims.append(im)
+        tables.append(table)
+    if not todo:
+        return out
+    k = len(todo)
+    if k == 1:
+        i, im = todo[0], ims[0]
+        if lib.mic_png_decode_rows(blobs[i], len(blobs[i]), _P(tables[0]), im.size[0], im.size[1]) == 0:
+            out[i] = im
+        return out
+    pngs = (ctypes.c_char_p * k)(*[blobs[i] for i in todo])
+    sizes = (ctypes.c_size_t * k)(*[len(blobs[i]) for i in todo])
+    rows = (_P * k)(*tables)
+    ws = (ctypes.c_int32 * k)(*[im.size[0] for im in ims])
+    hs = (ctypes.c_int32 * k)(*[im.size[1] for im in ims])
+    status = (ctypes.c_int32 * k)()
+    if threads <= 0:
+        # a bundle's handful of small cutouts (~100 KB of PNG in all) decode in about a millisecond on one core: starting
+        # threads costs more than it saves; big files are dealt over the library's threads
+        threads = 1 if sum(len(blobs[i]) for i in todo) < (256 << 10) else min(k, 8)
+    lib.mic_png_decode_many(k, pngs, sizes, rows, ws, hs, int(threads), status)
+    for j, i in enumerate(todo):
+        if status[j] == 0:
+            out[i] = ims[j]
+    return out
+
+
+def decode(blob: bytes) -> Optional[Image.Image]:
+    """One PNG file in memory -> RGBA PIL image, or None where libmic's decoder declines it."""
+    return decode_many([blob])[0]
+
+
+def decode_counts() -> Tuple[int, int]:
+    """(files libmic has decoded, files it has declined) in this process: the fallback meter."""
+    a, b = ctypes.c_uint64(), ctypes.c_uint64()
+    _native.lib().mic_png_decode_counts(ctypes.byref(a), ctypes.byref(b))
+    return int(a.value), int(b.value)
+
+
 def save_like_pil(image: Image.Image, path, **pil_kwargs) -> None:
     """image.save(path) as the reference's helpers call it (_save_overlay_debug, _compose_candidates_grid): PIL picks
     the format from the file name, so only *.png goes through libmic's writer; any other name (or explicit PIL

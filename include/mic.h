@@ -265,6 +265,24 @@ int mic_png_write_async(const char *path, const void *const *rows_host, int32_t 
                         int threads, int64_t *job);
 int mic_png_wait(int64_t job);
 
+/* ---- PNG reader: replaces Image.open(path).convert("RGBA") behind load_object_images (compositor.py:25-35, re-run
+ * every iteration at macro_placement_test.py:1493, 1679) and the background loader (background_resizing.py:6-8).
+ * Host-only.  Takes the PNG kinds this path meets -- 8-bit RGBA / RGB / grey / grey + alpha, palette images of 1-8 bits
+ * with or without tRNS, non-interlaced -- and produces exactly the bytes Pillow's convert("RGBA") holds.  Anything else
+ * is DECLINED, never guessed: MIC_ERR_UNSUPPORTED for a valid PNG of another kind (16-bit samples, Adam7, a tRNS colour
+ * key, APNG), MIC_ERR_FORMAT for anything irregular (bad signature / CRC / Adler-32 / Huffman code, truncated or
+ * trailing data); the Python binding hands such a file to Pillow, which decodes it or raises its own error.
+ * mic_png_info: size of the image, and whether the decoder takes the file.  mic_png_decode / _rows: into caller memory
+ * (stride_bytes >= width * 4; one pointer per row).  mic_png_decode_many: n files on up to `threads` library threads
+ * (<= 0: min(n, 8)); status[i] receives each file's result, the call returns the first failure (0: all decoded).
+ * mic_png_decode_counts: files this process has decoded / declined so far (a caller's fallback meter).            */
+int mic_png_info(const void *png, size_t bytes, int32_t *width, int32_t *height);
+int mic_png_decode(const void *png, size_t bytes, void *rgba_out, size_t stride_bytes, int32_t width, int32_t height);
+int mic_png_decode_rows(const void *png, size_t bytes, void *const *rows_host, int32_t width, int32_t height);
+int mic_png_decode_many(int32_t n, const void *const *pngs, const size_t *bytes, void *const *const *rows_host,
+                        const int32_t *widths, const int32_t *heights, int threads, int32_t *status);
+int mic_png_decode_counts(uint64_t *decoded, uint64_t *declined);
+
 /* ---- layout: the integer half of render() -------------------------------------------------
  * Flex-DSL JSON text ({"root": {...}}) + cutout sizes + canvas size -> object ids and clamped boxes
  * in depth-first order: _measure_flex_node / _place_flex_container / _clamp_boxes_to_canvas

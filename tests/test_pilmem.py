@@ -108,3 +108,79 @@ def test_same_pixels_is_an_exact_byte_comparison():
         assert _pilmem.same_pixels(im1, im2)
     assert not _pilmem.same_pixels(Image.new("RGBA", (4, 4)), Image.new("RGBA", (4, 5)))
     assert not _pilmem.same_pixels(Image.new("RGBA", (4, 4)), Image.new("RGB", (4, 4)))
+
+
+class _FakeCore:
+    def __init__(self, capsule):
+        self.ptr = capsule
+
+
+class _FakeImage:
+    """What _pilmem reads of a PIL image (mode, size, load, getpixel, im.ptr), over a hand-built ImagingMemoryInstance."""
+
+    def __init__(self, pixels, capsule):
+        self.mode, self.size, self._px, self.im, self.readonly = "RGBA", (pixels.shape[1], pixels.shape[0]), pixels, _FakeCore(capsule), 0
+
+    def load(self):
+        return None
+
+    def getpixel(self, xy):
+        return tuple(int(v) for v in self._px[xy[1], xy[0]])
+
+
+def _synthetic_imaging(pixels, layout, blocks=2):
+    """A struct laid out like ImagingMemoryInstance of the given _pilmem._LAYOUTS entry (bands, xsize, ysize, char **image,
+    pixelsize, linesize at those offsets; everything else junk), its rows in `blocks` separately allocated pieces, wrapped
+    in a PyCapsule named like Pillow's."""
+    import ctypes
+    H, W = pixels.shape[:2]
+    o_bands, o_x, o_y, o_image, o_px, o_line = layout
+    keep = []
+    rows = (ctypes.c_uint64 * H)()
+    per = -(-H // blocks)
+    for b0 in range(0, H, per):
+        piece = pixels[b0:b0 + per].copy()  # a block of its own, as Pillow's allocator hands them out
+        keep.append(piece)
+        for y in range(piece.shape[0]):
+            rows[b0 + y] = piece.ctypes.data + y * W * 4
+    struct_bytes = (ctypes.c_uint8 * 128)(*([0xAB] * 128))
+    base = ctypes.addressof(struct_bytes)
+    for off, val in ((o_bands, 4), (o_x, W), (o_y, H), (o_px, 4), (o_line, 4 * W)):
+        ctypes.c_int32.from_address(base + off).value = val
+    ctypes.c_uint64.from_address(base + o_image).value = ctypes.addressof(rows)
+    new = ctypes.pythonapi.PyCapsule_New
+    new.restype, new.argtypes = ctypes.py_object, [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p]
+    name = ctypes.c_char_p(b"PIL Imaging")
+    keep += [rows, struct_bytes, name]
+    return new(base, name, None), keep
+
+
+@pytest.mark.parametrize("which", [0, 1])
+def test_both_struct_layouts_on_a_synthetic_imaging_struct(which, monkeypatch):
+    """Only one Pillow is installed here (12.x: layout 0); the reference pins 11.3.0 (layout 1: the mode is a char[7]
+    in front of the fields instead of a 4-byte enum).  Both layouts are exercised against a hand-built struct: the rows
+    are found, copied and compared exactly, the report names the layout, and a struct that fits neither is refused."""
+    rng = np.random.default_rng(5 + which)
+    px = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    monkeypatch.setattr(_pilmem, "_good_layout", None)
+    monkeypatch.setattr(_pilmem, "counters", {"zero_copy": 0, "fallback": 0})
+    cap, keep = _synthetic_imaging(px, _pilmem._LAYOUTS[which])
+    fake = _FakeImage(px, cap)
+    runs = _pilmem.row_runs(fake)
+    assert runs is not None and sum(n for _, n in runs) == px.size and 1 <= len(runs) <= 2
+    assert _pilmem.path_report()["layout"] == _pilmem._LAYOUT_NAMES[which]
+    dst = np.zeros(px.size, np.uint8)
+    assert _pilmem.copy_to(fake, dst.ctypes.data) and np.array_equal(dst.reshape(px.shape), px)
+    tab = _pilmem.row_table(fake)
+    assert tab is not None and tab[1:] == (53, 37)
+    other = _FakeImage(px.copy(), _synthetic_imaging(px.copy(), _pilmem._LAYOUTS[which], blocks=3)[0])
+    assert _pilmem.same_pixels(fake, other)
+    assert _pilmem.path_report()["zero_copy"] >= 3 and _pilmem.path_report()["fallback"] == 0
+    # a struct of neither layout (fields shifted by 4 bytes): refused, counted as a fallback, nothing read through it
+    monkeypatch.setattr(_pilmem, "_good_layout", None)
+    shifted = tuple(o + 4 for o in _pilmem._LAYOUTS[which])
+    if shifted not in _pilmem._LAYOUTS:
+        bad = _FakeImage(px, _synthetic_imaging(px, shifted)[0])
+        assert _pilmem.row_runs(bad) is None and _pilmem.row_table(bad) is None
+        assert _pilmem.path_report()["fallback"] >= 2 and _pilmem.path_report()["layout"] is None
+    del keep

