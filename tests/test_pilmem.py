@@ -173,14 +173,16 @@ def test_both_struct_layouts_on_a_synthetic_imaging_struct(which, monkeypatch):
     assert _pilmem.copy_to(fake, dst.ctypes.data) and np.array_equal(dst.reshape(px.shape), px)
     tab = _pilmem.row_table(fake)
     assert tab is not None and tab[1:] == (53, 37)
-    other = _FakeImage(px.copy(), _synthetic_imaging(px.copy(), _pilmem._LAYOUTS[which], blocks=3)[0])
+    cap2, keep2 = _synthetic_imaging(px.copy(), _pilmem._LAYOUTS[which], blocks=3)
+    other = _FakeImage(px.copy(), cap2)
     assert _pilmem.same_pixels(fake, other)
     assert _pilmem.path_report()["zero_copy"] >= 3 and _pilmem.path_report()["fallback"] == 0
     # a struct of neither layout (fields shifted by 4 bytes): refused, counted as a fallback, nothing read through it
     monkeypatch.setattr(_pilmem, "_good_layout", None)
     shifted = tuple(o + 4 for o in _pilmem._LAYOUTS[which])
     if shifted not in _pilmem._LAYOUTS:
-        bad = _FakeImage(px, _synthetic_imaging(px, shifted)[0])
+        cap3, keep3 = _synthetic_imaging(px, shifted)
+        bad = _FakeImage(px, cap3)
         assert _pilmem.row_runs(bad) is None and _pilmem.row_table(bad) is None
         assert _pilmem.path_report()["fallback"] >= 2 and _pilmem.path_report()["layout"] is None
-    del keep
+    del keep, keep2
