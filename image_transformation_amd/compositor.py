@@ -539,12 +539,28 @@ def load_object_images(results_json_path: str, shared: bool = False) -> Dict[int
     base = os.path.dirname(results_json_path)
     out = ObjectImages()
     keys = []
-    paths = [os.path.join(base, it["filename"]) for it in items]
-    images = _DecodeCache.open_many(paths, shared)  # (files not seen before are decoded together)
-    for it, path, im in zip(items, paths, images):
-        out[int(it["object_id"])] = im
+    # The reference opens the entries one after another (compositor.py:31-34): the FIRST entry that is malformed, names
+    # a missing file or holds a broken image is the error the caller hears about.  Here the files not seen before are
+    # decoded together, so the entries are walked first (id, file name, the file's existence) up to the first failure,
+    # the ones before it are decoded (an earlier broken image raises there), and only then is that failure raised.
+    oids, paths, failure = [], [], None
+    for it in items:
+        try:
+            oid = int(it["object_id"])
+            path = os.path.join(base, it["filename"])
+            os.stat(path)
+        except Exception as exc:  # noqa: BLE001  (re-raised below, in the reference's order)
+            failure = exc
+            break
+        oids.append(oid)
+        paths.append(path)
+    images = _DecodeCache.open_many(paths, shared)
+    if failure is not None:
+        raise failure
+    for oid, path, im in zip(oids, paths, images):
+        out[oid] = im
         st = os.stat(path)
-        keys.append((int(it["object_id"]), os.path.abspath(path), st.st_mtime_ns, st.st_size))
+        keys.append((oid, os.path.abspath(path), st.st_mtime_ns, st.st_size))
     out._source_key = tuple(keys)  # (after the inserts above, which reset it)
     if shared:
         out._cores = {k: getattr(im, "im", None) for k, im in out.items()}
