@@ -632,7 +632,7 @@ def main():
     # measured separately with rocprofv3 (bench.py cannot run under --pmc and time itself) and committed under
     # profiles/; only quoted for the workload they were measured on.
     traffic, traffic_src, rocprof_kernel_ms = None, None, None
-    for name in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             with open(tpath) as f:

@@ -132,12 +132,29 @@ struct CoefEntry {
 // Device buffer of one axis' fragment tables.  Ref-counted: the context's cache holds one reference,
 // every plan whose tables point into the buffer another, so the cache can drop old entries (a service
 // that keeps meeting new sizes) without pulling memory from under a persistent plan.
+// One device allocation that many axis tables are carved from (bump allocation, freed when its last table dies): a new
+// box size used to cost a hipMalloc + three synchronous hipMemcpy per axis -- ~0.25 ms each, ~2 ms for the first LANCZOS
+// call on a bundle -- now its tables are a slice of the current slab, filled by ONE asynchronous copy out of a pinned ring.
+struct TableSlab {
+    void *dev = nullptr;
+    size_t cap = 0, used = 0;
+    int device = 0;
+    ~TableSlab() {
+        if (!dev) return;
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        (void)hipFree(dev);
+        if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+    }
+};
 struct FragBuffer {
     void *dev = nullptr;
     size_t bytes = 0;
     int device = 0;  // the last reference may die on a thread whose current device is another one
+    std::shared_ptr<TableSlab> slab;  // set: `dev` is a slice of this slab (kept alive, not freed here)
     ~FragBuffer() {
-        if (!dev) return;
+        if (!dev || slab) return;
         int cur = -1;
         (void)hipGetDevice(&cur);
         if (cur != device) (void)hipSetDevice(device);
@@ -169,6 +186,16 @@ struct mic_ctx {
     std::map<CoefKey, CoefEntry> coefs;
     std::map<CoefKey, FragEntry> frags;  // key.transposed unused (0)
     std::deque<CoefKey> frag_order;      // insertion order, for eviction
+    std::shared_ptr<TableSlab> table_slab;  // the slab new axis tables are carved from
+    struct TableStage {                  // pinned ring the tables are uploaded through (asynchronously, on the call's stream)
+        void *host = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;
+        bool pending = false;
+    };
+    static constexpr int kTableStages = 4;
+    TableStage table_stage[kTableStages];
+    int next_table_stage = 0;
     size_t frag_bytes = 0;
     size_t frag_cache_cap = kFragCacheBytes;  // MIC_FRAG_CACHE_MB at mic_create (tests shrink it)
     // Work units a call's resampled layers must add up to before they take the marching kernel (two workgroups
@@ -303,6 +330,11 @@ extern "C" int mic_destroy(mic_ctx *ctx) {
     for (hipEvent_t ev : ctx->prof_events) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : ctx->dl_event)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto &t : ctx->table_stage) {
+        if (t.host) (void)hipHostFree(t.host);
+        if (t.ev) (void)hipEventDestroy(t.ev);
+    }
+    ctx->table_slab.reset();
     for (auto &r : ctx->layer_regions)
         if (r.dev) (void)hipFree(r.dev);
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -391,7 +423,10 @@ static int get_coefs(mic_ctx *ctx, int in, int out, int filter, bool transposed,
 }
 
 // in == out: the identity table (Pillow skips that pass; one tap of weight 1.0 gives the same bytes).
-static int get_frags(mic_ctx *ctx, int in, int out, int filter, FragEntry *res) {
+// A table met for the first time is carved from the context's current slab and uploaded by one asynchronous copy on
+// `stream` (the stream of the call that needs it: its kernels follow on the same stream; a later call on another stream
+// is ordered behind it by adopt_stream()).
+static int get_frags(mic_ctx *ctx, int in, int out, int filter, hipStream_t stream, FragEntry *res) {
     const CoefKey key{in, out, in == out ? -1 : filter, 0};
     auto it = ctx->frags.find(key);
     if (it != ctx->frags.end()) {
@@ -406,7 +441,7 @@ static int get_frags(mic_ctx *ctx, int in, int out, int filter, FragEntry *res) 
     const size_t bias_b = align_up(f.bias.size() * sizeof(int32_t), 64);
     e.buf = std::make_shared<FragBuffer>();
     e.buf->device = ctx->device;
-    e.buf->bytes = meta_b + bias_b + f.frags.size();
+    e.buf->bytes = align_up(meta_b + bias_b + f.frags.size(), 256);
     // bounded cache, oldest first (entries a live plan still points into stay allocated until it dies)
     while (!ctx->frag_order.empty() && ctx->frag_bytes + e.buf->bytes > ctx->frag_cache_cap) {
         auto old = ctx->frags.find(ctx->frag_order.front());
@@ -416,14 +451,43 @@ static int get_frags(mic_ctx *ctx, int in, int out, int filter, FragEntry *res) 
             ctx->frags.erase(old);
         }
     }
-    HIP_TRY(hipMalloc(&e.buf->dev, e.buf->bytes));
+    // a slice of the current slab (a new slab when it is full: 4 MiB, or the table's own size)
+    if (!ctx->table_slab || ctx->table_slab->used + e.buf->bytes > ctx->table_slab->cap) {
+        auto slab = std::make_shared<TableSlab>();
+        slab->device = ctx->device;
+        slab->cap = std::max(e.buf->bytes, (size_t)4 << 20);
+        HIP_TRY(hipMalloc(&slab->dev, slab->cap));
+        ctx->table_slab = std::move(slab);
+    }
+    e.buf->slab = ctx->table_slab;
+    e.buf->dev = static_cast<char *>(ctx->table_slab->dev) + ctx->table_slab->used;
+    ctx->table_slab->used += e.buf->bytes;
     e.meta = reinterpret_cast<uint64_t>(e.buf->dev);
     e.bias = e.meta + meta_b;
     e.frags = e.bias + bias_b;
-    // Pageable sources: the runtime stages them before returning.
-    HIP_TRY(hipMemcpy(reinterpret_cast<void *>(e.meta), f.meta.data(), f.meta.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(reinterpret_cast<void *>(e.bias), f.bias.data(), f.bias.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(reinterpret_cast<void *>(e.frags), f.frags.data(), f.frags.size(), hipMemcpyHostToDevice));
+    // one pinned stage of the ring, one asynchronous copy
+    mic_ctx::TableStage &st = ctx->table_stage[ctx->next_table_stage];
+    ctx->next_table_stage = (ctx->next_table_stage + 1) % mic_ctx::kTableStages;
+    if (!st.ev) HIP_TRY(hipEventCreateWithFlags(&st.ev, hipEventDisableTiming));
+    if (st.pending) {
+        HIP_TRY(hipEventSynchronize(st.ev));
+        st.pending = false;
+    }
+    if (st.cap < e.buf->bytes) {
+        if (st.host) HIP_TRY(hipHostFree(st.host));
+        st.host = nullptr;
+        st.cap = 0;
+        const size_t cap = align_up(std::max(e.buf->bytes, (size_t)512 << 10), 4096);
+        HIP_TRY(hipHostMalloc(&st.host, cap, 0));
+        st.cap = cap;
+    }
+    char *hp = static_cast<char *>(st.host);
+    memcpy(hp, f.meta.data(), f.meta.size() * sizeof(int32_t));
+    memcpy(hp + meta_b, f.bias.data(), f.bias.size() * sizeof(int32_t));
+    memcpy(hp + meta_b + bias_b, f.frags.data(), f.frags.size());
+    HIP_TRY(hipMemcpyAsync(e.buf->dev, st.host, meta_b + bias_b + f.frags.size(), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(st.ev, stream));
+    st.pending = true;
     e.meta_host = std::make_shared<std::vector<int32_t>>(f.meta);
     ctx->frags[key] = e;
     ctx->frag_order.push_back(key);
@@ -699,10 +763,10 @@ int window_needed(const std::vector<int32_t> &meta, int tiles, int per) {
 // Pick the workgroup tile of the tile kernel for one layer: the biggest of a short list whose source planes +
 // intermediate planes fit LDS, preferring sizes that let three workgroups share a CU.  Leaves tx16 == 0 when
 // nothing fits (extreme shrinks: the two-pass kernels take those).
-int choose_tile(mic_ctx *ctx, ResizePlan *p, int filter) {
+int choose_tile(mic_ctx *ctx, ResizePlan *p, int filter, hipStream_t stream) {
     FragEntry fh, fv;
-    if (int rc = get_frags(ctx, p->sw, p->dw, filter, &fh)) return rc;
-    if (int rc = get_frags(ctx, p->sh, p->dh, filter, &fv)) return rc;
+    if (int rc = get_frags(ctx, p->sw, p->dw, filter, stream, &fh)) return rc;
+    if (int rc = get_frags(ctx, p->sh, p->dh, filter, stream, &fv)) return rc;
     static const int kTiles[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
     p->tx16 = 0;
     if ((int64_t)p->sw * p->sh < 4) return MIC_OK;  // the kernel's 16-byte loads need 4 pixels to clamp into
@@ -734,10 +798,10 @@ int choose_tile(mic_ctx *ctx, ResizePlan *p, int filter) {
 // Does the layer qualify for the marching kernel, and with what LDS: the source band covers what the 4 x-tiles of
 // a strip can touch, the ring holds the 16-row slots between the first and the last tap row of any tile of 16
 // output rows (a tile is emitted as soon as its last band is in).
-int choose_march(mic_ctx *ctx, ResizePlan *p, int filter) {
+int choose_march(mic_ctx *ctx, ResizePlan *p, int filter, hipStream_t stream) {
     FragEntry fh, fv;
-    if (int rc = get_frags(ctx, p->sw, p->dw, filter, &fh)) return rc;
-    if (int rc = get_frags(ctx, p->sh, p->dh, filter, &fv)) return rc;
+    if (int rc = get_frags(ctx, p->sw, p->dw, filter, stream, &fh)) return rc;
+    if (int rc = get_frags(ctx, p->sh, p->dh, filter, stream, &fv)) return rc;
     p->march_ok = false;
     if (fh.max_chunks != 1 || fv.max_chunks != 1) return MIC_OK;  // the kernel has no chunk loops
     int pitch_c = round16(window_touched(*fh.meta_host, fh.tiles, 4));
@@ -779,7 +843,7 @@ int64_t march_unit_px(int64_t total_px) {
     return std::max<int64_t>(64 * 48, std::min<int64_t>(total_px / target_units, 16 * 1024));
 }
 
-int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, void *scratch, PassTables *pt) {
+int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, void *scratch, hipStream_t stream, PassTables *pt) {
     const uint64_t arena = reinterpret_cast<uint64_t>(scratch);
     int64_t march_px = 0;
     for (const ResizePlan &p : plans)
@@ -791,8 +855,8 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
         const uint64_t dst = p.dst_ptr ? p.dst_ptr : arena + p.dst_off;
         if (p.march) {
             FragEntry fh, fv;
-            if (int rc = get_frags(ctx, p.sw, p.dw, filter, &fh)) return rc;
-            if (int rc = get_frags(ctx, p.sh, p.dh, filter, &fv)) return rc;
+            if (int rc = get_frags(ctx, p.sw, p.dw, filter, stream, &fh)) return rc;
+            if (int rc = get_frags(ctx, p.sh, p.dh, filter, stream, &fv)) return rc;
             pt->frag_refs.push_back(fh.buf);
             pt->frag_refs.push_back(fv.buf);
             RsMarch f{};
@@ -814,8 +878,8 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
         }
         if (p.tx16 > 0) {
             FragEntry fh, fv;
-            if (int rc = get_frags(ctx, p.sw, p.dw, filter, &fh)) return rc;
-            if (int rc = get_frags(ctx, p.sh, p.dh, filter, &fv)) return rc;
+            if (int rc = get_frags(ctx, p.sw, p.dw, filter, stream, &fh)) return rc;
+            if (int rc = get_frags(ctx, p.sh, p.dh, filter, stream, &fv)) return rc;
             pt->frag_refs.push_back(fh.buf);
             pt->frag_refs.push_back(fv.buf);
             RsTile f{};
@@ -944,8 +1008,10 @@ static uint64_t layer_cache_alloc(mic_ctx *ctx, size_t bytes) {
             r.used += bytes;
             return at;
         }
-    // a new region: big enough for this layer, 128 MiB otherwise, inside the cap
-    size_t want = std::max(bytes + kPixelAlign, (size_t)128 << 20);
+    // a new region: big enough for this layer; otherwise 32 MiB for the first one (a bundle's thumbnails and a few
+    // resized cutouts: the first LANCZOS call of a process should not wait for a 128 MiB allocation), doubling up to
+    // 128 MiB; inside the cap
+    size_t want = std::max(bytes + kPixelAlign, std::min<size_t>((size_t)128 << 20, std::max<size_t>((size_t)32 << 20, 2 * ctx->layer_cache_total)));
     if (ctx->layer_cache_total + want > ctx->layer_cache_cap) want = ctx->layer_cache_cap - std::min(ctx->layer_cache_cap, ctx->layer_cache_total);
     if (want < bytes + kPixelAlign) return 0;
     mic_ctx::LayerRegion r;
@@ -1105,8 +1171,8 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                     rp.src = reinterpret_cast<uint64_t>(A->blob) + E.offset;
                     rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
                     rp.atlas = Pl.atlas; rp.entry = it->second;
-                    if (int rc = choose_march(ctx, &rp, filter)) return rc;
-                    if (int rc = choose_tile(ctx, &rp, filter)) return rc;
+                    if (int rc = choose_march(ctx, &rp, filter, stream)) return rc;
+                    if (int rc = choose_tile(ctx, &rp, filter, stream)) return rc;
                     plan_idx = plans.size();
                     plans.push_back(rp);
                     dedup.emplace(key, plan_idx);
@@ -1192,7 +1258,7 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
         }
         if (used) P->pt.frag_refs.push_back(A->planar);  // the pass tables point into it
     }
-    if (int rc = plan_passes(ctx, plans, filter, scratch, &P->pt)) return rc;
+    if (int rc = plan_passes(ctx, plans, filter, scratch, stream, &P->pt)) return rc;
     plan_offsets(P);
     if (persistent && P->total > 0) {
         HIP_TRY(hipMalloc(&P->tables_dev, P->total));
@@ -1650,13 +1716,13 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
     rp.dst_ptr = reinterpret_cast<uint64_t>(dst_dev);
     // a single image: the tile kernel (it premultiplies and planarises the window while loading it; the marching
     // kernel would first need a planar copy of the whole source, and one image rarely fills the chip with its units)
-    if (int rc = choose_tile(ctx, &rp, filter)) return rc;
+    if (int rc = choose_tile(ctx, &rp, filter, stream)) return rc;
     size_t need = 0;
     if (rp.tx16 == 0 && dst_w != src_w && dst_h != src_h) need = (size_t)dst_w * src_h * 4 + kGuard;
     if (int rc = ensure_arena(ctx, need)) return rc;
     PassTables pt;
     std::vector<ResizePlan> plans{rp};
-    if (int rc = plan_passes(ctx, plans, filter, ctx->arena, &pt)) return rc;
+    if (int rc = plan_passes(ctx, plans, filter, ctx->arena, stream, &pt)) return rc;
     const size_t off_v = 64, off_t = 128;
     const size_t total = off_t + sizeof(RsTile) * std::max<size_t>(1, pt.tiles.size());
     Slot *slot = nullptr;

@@ -21,6 +21,7 @@ plans = [CompositeBatch(atlas, [canvas], [coerce_placements(atlas, big[f"c5_audi
 outs = [plans[0].alloc_outputs() for _ in range(3)]
 for k in range(n):
     for p in plans:
+        p.invalidate()  # (cold: the x8 upscales are resampled in every run; the refine loop itself finds them resident)
         p.run(outs[k % 3])
 torch.cuda.synchronize()
 print([p.stats() for p in plans][:1])

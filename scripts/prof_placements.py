@@ -8,7 +8,10 @@ size, objs, pl = synthetic.placements_workload(3840, 2160, 32, 3, os.environ.get
 atlas = Atlas(objs)
 plan = CompositeBatch(atlas, [SolidCanvas(size, synthetic.SOLID_BG)], [coerce_placements(atlas, pl)])
 out = plan.alloc_outputs()
+cold = os.environ.get("MIC_WARM") != "1"  # default: every run resamples again (mic_plan_invalidate); MIC_WARM=1: layers resident
 for _ in range(int(os.environ.get("MIC_ITERS", "6"))):
+    if cold:
+        plan.invalidate()
     plan.run(out)
 torch.cuda.synchronize()
 print(plan.stats())
