@@ -4,11 +4,12 @@
 // Pillow's crop + AlphaComposite.c + paste triple pass (Image.alpha_composite(im, dest)).
 //
 // Mapping (gfx950, wave64).  The canvas is a linear stream of RGBA words cut into 4 KiB pages
-// aligned to absolute address.  One workgroup = ONE WAVEFRONT = one page: a lane owns four groups
-// of four adjacent pixels, 1 KiB apart, so the page is written by four fully coalesced 1 KiB
-// stores.  Workgroups are dealt round-robin over the 8 XCDs, so in dispatch order every XCD keeps
-// writing one residue class of pages (mod 8); on MI355X that is what lets a store stream reach
-// ~6.7 TB/s (see mic_internal.h and scripts/streambench.hip).
+// aligned to absolute address.  One WAVEFRONT = one page: a lane owns four groups of four adjacent
+// pixels, 1 KiB apart, so the page is written by four fully coalesced 1 KiB stores; a workgroup is
+// kPagesPerWorkgroup (4) such waves over consecutive pages, sharing nothing.  Workgroups are dealt
+// round-robin over the 8 XCDs, so in dispatch order every XCD keeps writing one residue class of
+// 16 KiB page groups (mod 8); whole pages per wave in dispatch order are what lets a store stream
+// reach ~6.7 TB/s on MI355X (see mic_internal.h and scripts/streambench.hip).
 //
 // Layer culling happens inside the wave, 64 layers at a time: lane l loads layer record l and tests
 // its rectangle against the page's four 256-pixel runs (a handful of integer compares, exact at run
@@ -215,11 +216,17 @@ enum : int { kFromTables = 0, kJobInArgs = 1, kAllInArgs = 2 };
 struct LayerPack {
     Layer l[kPackLayers];
 };
+// Workgroup = kPagesPerWorkgroup waves, each with a page of its own (nothing is shared between them: no LDS, no
+// barrier).  Round 4, A/B in one run against one-wave workgroups (profiles/r04_composite_pages_per_workgroup.txt): four
+// pages per workgroup is 3-5 % faster on a single 4K canvas (a quarter of the workgroups to dispatch for the same waves:
+// 12.3 -> 11.9 us between events, 10.0 -> 9.5 us per canvas back to back) and 2.4 % on the 16-canvas batch (113.9 ->
+// 111.2 us); two are level with one, eight lose 7 %.
 template <bool ALIGNED, bool SOLID, int MODE>
-__global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6 : 4)) void composite_kernel(
+__global__ __launch_bounds__(64 * kPagesPerWorkgroup, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6 : 4)) void composite_kernel(
     const Job *__restrict__ jobs, const Layer *__restrict__ layers, const Job one, const LayerPack pack) {
     Job job = MODE != kFromTables ? one : jobs[blockIdx.y];
-    if ((int)blockIdx.x >= job.n_pages) return;
+    const int page_ = (int)blockIdx.x * kPagesPerWorkgroup + (kPagesPerWorkgroup > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0);
+    if (page_ >= job.n_pages) return;
     // A solid colour that lives in device memory (mic_job.bg_rgba_dev: the median kernel's result, consumed without a
     // host round trip): one scalar load, in flight while the layer records are fetched.  The host classes such a job
     // as SOLID (opaque); a colour word that turns out not to be opaque sends the page through the exact per-pixel path
@@ -229,12 +236,12 @@ __global__ __launch_bounds__(64, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6
         job.bg_rgba = *reinterpret_cast<const MIC_GLOBAL uint32_t *>(job.bg);
         job.bg = 0;
     }
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int W = job.W;
     const int64_t n_px = (int64_t)job.W * job.H;
     const Layer *jl = MODE == kAllInArgs ? pack.l : layers + job.layer_begin;
 
-    const int64_t qp = (int64_t)blockIdx.x * kPagePx - job.px_shift;
+    const int64_t qp = (int64_t)page_ * kPagePx - job.px_shift;
     // pages that lie wholly inside the canvas: all but the first/last of a page-misaligned canvas
     if (qp < 0 || W < kLaneNPx) {
         edge_page(job, jl, qp, lane);
@@ -493,33 +500,33 @@ hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_
             if (one.layer_count > 0) memcpy(g_pack.l, single_layers_host + one.layer_begin, sizeof(Layer) * (size_t)one.layer_count);
             one.layer_begin = 0;
             switch (cls) {
-                case 0: hipLaunchKernelGGL((composite_kernel<true, true, kAllInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
-                case 1: hipLaunchKernelGGL((composite_kernel<false, true, kAllInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
-                case 2: hipLaunchKernelGGL((composite_kernel<true, false, kAllInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
-                default: hipLaunchKernelGGL((composite_kernel<false, false, kAllInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+                case 0: hipLaunchKernelGGL((composite_kernel<true, true, kAllInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+                case 1: hipLaunchKernelGGL((composite_kernel<false, true, kAllInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+                case 2: hipLaunchKernelGGL((composite_kernel<true, false, kAllInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+                default: hipLaunchKernelGGL((composite_kernel<false, false, kAllInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
             }
             return hipGetLastError();
         }
         switch (cls) {
-            case 0: hipLaunchKernelGGL((composite_kernel<true, true, kJobInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
-            case 1: hipLaunchKernelGGL((composite_kernel<false, true, kJobInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
-            case 2: hipLaunchKernelGGL((composite_kernel<true, false, kJobInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
-            default: hipLaunchKernelGGL((composite_kernel<false, false, kJobInArgs>), grid, dim3(64), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
+            case 0: hipLaunchKernelGGL((composite_kernel<true, true, kJobInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
+            case 1: hipLaunchKernelGGL((composite_kernel<false, true, kJobInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
+            case 2: hipLaunchKernelGGL((composite_kernel<true, false, kJobInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
+            default: hipLaunchKernelGGL((composite_kernel<false, false, kJobInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
         }
         return hipGetLastError();
     }
     const Job none{};
     if (b[1] > b[0])
-        hipLaunchKernelGGL((composite_kernel<true, true, kFromTables>), dim3((unsigned)pitch, (unsigned)(b[1] - b[0])), dim3(64),
+        hipLaunchKernelGGL((composite_kernel<true, true, kFromTables>), dim3((unsigned)pitch / kPagesPerWorkgroup, (unsigned)(b[1] - b[0])), dim3(64 * kPagesPerWorkgroup),
                            0, stream, jobs_dev + b[0], layers_dev, none, g_pack);
     if (b[2] > b[1])
-        hipLaunchKernelGGL((composite_kernel<false, true, kFromTables>), dim3((unsigned)pitch, (unsigned)(b[2] - b[1])), dim3(64),
+        hipLaunchKernelGGL((composite_kernel<false, true, kFromTables>), dim3((unsigned)pitch / kPagesPerWorkgroup, (unsigned)(b[2] - b[1])), dim3(64 * kPagesPerWorkgroup),
                            0, stream, jobs_dev + b[1], layers_dev, none, g_pack);
     if (b[3] > b[2])
-        hipLaunchKernelGGL((composite_kernel<true, false, kFromTables>), dim3((unsigned)pitch, (unsigned)(b[3] - b[2])), dim3(64),
+        hipLaunchKernelGGL((composite_kernel<true, false, kFromTables>), dim3((unsigned)pitch / kPagesPerWorkgroup, (unsigned)(b[3] - b[2])), dim3(64 * kPagesPerWorkgroup),
                            0, stream, jobs_dev + b[2], layers_dev, none, g_pack);
     if (b[4] > b[3])
-        hipLaunchKernelGGL((composite_kernel<false, false, kFromTables>), dim3((unsigned)pitch, (unsigned)(b[4] - b[3])), dim3(64),
+        hipLaunchKernelGGL((composite_kernel<false, false, kFromTables>), dim3((unsigned)pitch / kPagesPerWorkgroup, (unsigned)(b[4] - b[3])), dim3(64 * kPagesPerWorkgroup),
                            0, stream, jobs_dev + b[3], layers_dev, none, g_pack);
     return hipGetLastError();
 }

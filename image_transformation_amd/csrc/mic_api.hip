@@ -1358,7 +1358,9 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
                 if (spans[(size_t)ji].first < spans[(size_t)ji - 1].second)
                     return fail(MIC_ERR_INVALID, "two output canvases of the batch overlap");
         }
-        pitch = (max_pages + 7) / 8 * 8;
+        // (a multiple of 8 workgroups of kPagesPerWorkgroup pages: (linear workgroup id) mod 8 == (workgroup's index
+        // inside its canvas) mod 8 for every job of the launch)
+        pitch = (max_pages + 8 * kPagesPerWorkgroup - 1) / (8 * kPagesPerWorkgroup) * (8 * kPagesPerWorkgroup);
         // sort the job table by kernel class (see launch_composite): 0 = aligned + solid opaque
         // background (the pipeline's own canvases), 1 = unaligned + solid, 2 = aligned + other, 3 = rest
         auto job_class = [](const Job &d) {
@@ -1451,7 +1453,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         ++ctx->prof_calls;
     }
     if (P->persistent) P->resampled_valid = true;
-    P->stats.composite_blocks = (uint64_t)pitch * n_jobs;
+    P->stats.composite_blocks = (uint64_t)(pitch / kPagesPerWorkgroup) * n_jobs;
     ctx->stats = P->stats;
     return MIC_OK;
 }

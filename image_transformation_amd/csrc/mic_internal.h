@@ -25,7 +25,8 @@ typedef const MIC_GLOBAL int32_t *gciptr;
 constexpr int kLaneNPx = 4;                    // adjacent pixels per lane per group (16 B)
 constexpr int kWavePx = 64 * kLaneNPx;         // 256 px = 1 KiB per wave-wide access
 constexpr int kGroups = 4;                     // groups per lane, 1 KiB apart
-constexpr int kPagePx = kWavePx * kGroups;     // 1024 px = 4 KiB per workgroup
+constexpr int kPagePx = kWavePx * kGroups;     // 1024 px = 4 KiB per wave
+constexpr int kPagesPerWorkgroup = 4;          // waves (= consecutive pages) per composite workgroup
 
 // One resolved placement: where the layer's pixels live and where they land on the canvas.
 struct alignas(16) Layer {
