@@ -419,3 +419,11 @@ def layout_to_placements(layout: Any, images: Mapping[int, Any],
                     "flex_root")
     clamp_boxes(out, canvas_size)
     return out
+
+
+# The reference's (module-private) names, for callers that import the box maths by those names
+# (macro_placement_test.py:255-372, 637-964): same signatures, same results, same error messages.
+_measure_flex_node = measure
+_place_flex_container = place_container
+_clamp_boxes_to_canvas = clamp_boxes
+_sanitize_padding, _sanitize_pin, _sanitize_offset, _sanitize_stick_to = _norm_padding, _norm_pin, _norm_offset, _norm_stick_to

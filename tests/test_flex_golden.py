@@ -37,6 +37,23 @@ def test_random_trees_match_reference(flex_golden):
         assert clamped == case["clamped"], case["name"]
 
 
+def test_reference_names_are_the_same_functions(flex_golden):
+    """A maintainer of the reference swaps imports, not call sites: the box maths answers to the reference's own
+    (module-private) names with the reference's signatures (macro_placement_test.py:255-372, 637-964)."""
+    case = flex_golden["kat"][0]
+    sizes = {int(k): tuple(v) for k, v in case["sizes"].items()}
+    placed = []
+    flex._place_flex_container(case["layout"]["root"], (0, 0), tuple(case["canvas"]), sizes, placed, "flex_root")
+    assert placed == case["placed"]
+    assert list(flex._measure_flex_node(case["layout"]["root"], sizes)) == case["measured"]
+    flex._clamp_boxes_to_canvas(placed, tuple(case["canvas"]))
+    assert placed == case["clamped"]
+    assert flex._sanitize_padding(3, 7) == {"left": 3, "right": 3, "top": 3, "bottom": 3}
+    with pytest.raises(ValueError, match="must be non-negative"):
+        flex._sanitize_padding(-1, 7)
+    assert flex._sanitize_pin(None, 1) == {} and flex._sanitize_offset(None, 1) == {"x": 0, "y": 0} and flex._sanitize_stick_to(None, 1) == {}
+
+
 def test_nested_known_answers(flex_golden):
     kat = {c["name"]: c for c in flex_golden["kat"]}
     for case in kat.values():
