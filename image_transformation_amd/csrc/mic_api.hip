@@ -20,7 +20,10 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <new>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -186,6 +189,11 @@ struct mic_ctx {
     std::map<CoefKey, CoefEntry> coefs;
     std::map<CoefKey, FragEntry> frags;  // key.transposed unused (0)
     std::deque<CoefKey> frag_order;      // insertion order, for eviction
+    // one pinned buffer for the bulk upload of the axis tables a call builds ahead (prebuild_axis_frags)
+    void *bulk_host = nullptr;
+    size_t bulk_cap = 0;
+    hipEvent_t bulk_ev = nullptr;
+    bool bulk_pending = false;
     std::shared_ptr<TableSlab> table_slab;  // the slab new axis tables are carved from
     struct TableStage {                  // pinned ring the tables are uploaded through (asynchronously, on the call's stream)
         void *host = nullptr;
@@ -335,6 +343,8 @@ extern "C" int mic_destroy(mic_ctx *ctx) {
         if (t.ev) (void)hipEventDestroy(t.ev);
     }
     ctx->table_slab.reset();
+    if (ctx->bulk_host) (void)hipHostFree(ctx->bulk_host);
+    if (ctx->bulk_ev) (void)hipEventDestroy(ctx->bulk_ev);
     for (auto &r : ctx->layer_regions)
         if (r.dev) (void)hipFree(r.dev);
     if (ctx->arena) (void)hipFree(ctx->arena);
@@ -993,6 +1003,180 @@ static void plan_offsets(mic_plan *P) {
     P->total = align_up(P->off_v + sizeof(RsJob) * P->pt.v.size(), 64);
 }
 
+// A few parked host threads for short parallel loops (the axis tables of a call: 64 x ~60 us).  Starting threads per
+// call cost more than the work (1.15 ms for 0.5 ms of table building on 8 fresh threads, measured on the GPU box); parked
+// workers are woken through one condition variable.  run(n_parts, fn) calls fn(part) for every part in 0..n_parts-1, the
+// calling thread taking its share, and returns when all are done.  One loop at a time (callers hold a context lock;
+// two contexts take turns).
+class HostPool {
+  public:
+    static HostPool &get() {
+        static HostPool *pool = new HostPool();  // (never destroyed: its threads are parked for the life of the process)
+        return *pool;
+    }
+    int workers() const { return (int)threads_.size(); }
+    // false: some part threw (std::bad_alloc ...); every other part has still run
+    bool run(int n_parts, const std::function<void(int)> &fn) {
+        std::lock_guard<std::mutex> one_at_a_time(run_mu_);
+        failed_ = false;
+        fn_ = &fn;
+        n_parts_ = n_parts;
+        next_ = 0;
+        if (n_parts > 1 && !threads_.empty()) {
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                busy_ = (int)threads_.size();
+                ++generation_;
+            }
+            cv_.notify_all();
+            drain();
+            std::unique_lock<std::mutex> lk(mu_);
+            done_cv_.wait(lk, [&] { return busy_ == 0; });
+        } else {
+            drain();
+        }
+        fn_ = nullptr;
+        return !failed_;
+    }
+
+  private:
+    HostPool() {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const int n = (int)std::min<unsigned>(15, hw - 1);
+        try {
+            for (int i = 0; i < n; ++i) threads_.emplace_back([this] { loop(); });
+        } catch (...) {  // fewer workers than wanted: the loops still complete
+        }
+        for (auto &t : threads_) t.detach();
+    }
+    void drain() {
+        for (;;) {
+            const int i = next_.fetch_add(1);
+            if (i >= n_parts_) break;
+            try {
+                (*fn_)(i);
+            } catch (...) {  // (never let an exception leave a worker thread)
+                failed_ = true;
+            }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return generation_ != seen; });
+                seen = generation_;
+            }
+            drain();
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--busy_ == 0) done_cv_.notify_one();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int)> *fn_ = nullptr;
+    std::atomic<int> next_{0};
+    std::atomic<bool> failed_{false};
+    int n_parts_ = 0, busy_ = 0;
+    uint64_t generation_ = 0;
+};
+
+// Build the axis tables a call is about to need that the context has not seen -- on several host threads, straight
+// into ONE pinned buffer, uploaded by ONE asynchronous copy into one slice of table memory -- and enter them into the
+// cache.  A table is Pillow's precompute_coeffs in double precision: two libm sin() per tap, ~50 us per 1000-sample axis
+// on the GPU box's host, and a composite() whose 32 boxes all have new sizes needs 64 of them: 6 ms of host time in front
+// of 68 us of GPU work when built and uploaded one after another (scripts/time_new_sizes.py).  The tables are
+// independent; each thread runs the very same scalar code on its share (bit-identical: no vector maths, no reordering
+// inside a table).  Anything that goes wrong here is not an error: get_frags builds what is still missing.
+static void prebuild_axis_frags(mic_ctx *ctx, const std::vector<CoefKey> &keys, hipStream_t stream) {
+    const size_t n = keys.size();
+    if (n < 4) return;  // (waking the pool is worth it for a few tables at least)
+    std::vector<AxisTable> tables(n);
+    std::vector<AxisFrags> lay(n);
+    std::vector<size_t> chunks(n), off(n), meta_b(n), bias_b(n), bytes(n);
+    HostPool &pool = HostPool::get();
+    try {
+        if (!pool.run((int)n, [&](int i) {  // phase 1: the coefficient tables (the sin() calls) and the fragment layouts
+                const CoefKey &k = keys[(size_t)i];
+                tables[(size_t)i] = k.filter == -1 ? identity_axis_table(k.in) : build_axis_table(k.in, k.out, k.filter);
+                chunks[(size_t)i] = axis_frags_layout(tables[(size_t)i], &lay[(size_t)i]);
+            }))
+            return;
+        size_t total = 0;
+        for (size_t i = 0; i < n; ++i) {
+            meta_b[i] = align_up(lay[i].meta.size() * sizeof(int32_t), 64);
+            bias_b[i] = align_up((size_t)lay[i].tiles * 16 * sizeof(int32_t), 64);
+            bytes[i] = align_up(meta_b[i] + bias_b[i] + chunks[i] * 3072, 256);
+            off[i] = total;
+            total += bytes[i];
+        }
+        // the pinned buffer (grown geometrically; the previous bulk upload out of it must have landed)
+        if (ctx->bulk_pending) {
+            if (hipEventSynchronize(ctx->bulk_ev) != hipSuccess) return;
+            ctx->bulk_pending = false;
+        }
+        if (ctx->bulk_cap < total) {
+            if (ctx->bulk_host) (void)hipHostFree(ctx->bulk_host);
+            ctx->bulk_host = nullptr;
+            ctx->bulk_cap = 0;
+            const size_t cap = align_up(std::max(total + total / 2, (size_t)4 << 20), 4096);
+            if (hipHostMalloc(&ctx->bulk_host, cap, 0) != hipSuccess) { (void)hipGetLastError(); ctx->bulk_host = nullptr; return; }
+            ctx->bulk_cap = cap;
+        }
+        if (!ctx->bulk_ev && hipEventCreateWithFlags(&ctx->bulk_ev, hipEventDisableTiming) != hipSuccess) return;
+        // one slice of table memory for all of them (a slab of its own when the current one has no room)
+        if (!ctx->table_slab || ctx->table_slab->used + total > ctx->table_slab->cap) {
+            auto slab = std::make_shared<TableSlab>();
+            slab->device = ctx->device;
+            slab->cap = std::max(total, (size_t)4 << 20);
+            if (hipMalloc(&slab->dev, slab->cap) != hipSuccess) { (void)hipGetLastError(); return; }
+            ctx->table_slab = std::move(slab);
+        }
+        char *dev = static_cast<char *>(ctx->table_slab->dev) + ctx->table_slab->used;
+        char *hp = static_cast<char *>(ctx->bulk_host);
+        if (!pool.run((int)n, [&](int ii) {  // phase 2: meta | bias | fragments of every table, written in place
+                const size_t i = (size_t)ii;
+                char *at = hp + off[i];
+                memcpy(at, lay[i].meta.data(), lay[i].meta.size() * sizeof(int32_t));
+                fill_axis_frags(tables[i], lay[i], reinterpret_cast<int32_t *>(at + meta_b[i]),
+                                reinterpret_cast<int8_t *>(at + meta_b[i] + bias_b[i]), chunks[i]);
+            }))
+            return;
+        if (hipMemcpyAsync(dev, hp, total, hipMemcpyHostToDevice, stream) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipEventRecord(ctx->bulk_ev, stream) != hipSuccess) return;
+        ctx->bulk_pending = true;
+        ctx->table_slab->used += total;
+        for (size_t i = 0; i < n; ++i) {
+            FragEntry e;
+            e.tiles = lay[i].tiles;
+            e.max_chunks = lay[i].max_chunks;
+            e.buf = std::make_shared<FragBuffer>();
+            e.buf->device = ctx->device;
+            e.buf->bytes = bytes[i];
+            e.buf->slab = ctx->table_slab;
+            e.buf->dev = dev + off[i];
+            e.meta = reinterpret_cast<uint64_t>(e.buf->dev);
+            e.bias = e.meta + meta_b[i];
+            e.frags = e.bias + bias_b[i];
+            e.meta_host = std::make_shared<std::vector<int32_t>>(std::move(lay[i].meta));
+            while (!ctx->frag_order.empty() && ctx->frag_bytes + e.buf->bytes > ctx->frag_cache_cap) {
+                auto old = ctx->frags.find(ctx->frag_order.front());
+                ctx->frag_order.pop_front();
+                if (old != ctx->frags.end()) {
+                    ctx->frag_bytes -= old->second.buf->bytes;
+                    ctx->frags.erase(old);
+                }
+            }
+            ctx->frags[keys[i]] = e;
+            ctx->frag_order.push_back(keys[i]);
+            ctx->frag_bytes += e.buf->bytes;
+        }
+    } catch (const std::exception &) {  // (bad_alloc, system_error: the tables are then built one by one, as needed)
+    }
+}
+
 // ---- resident layer cache (see mic_ctx) -----------------------------------------------------------------------------
 static size_t layer_bytes(const ResizePlan &rp) { return align_up((size_t)rp.dw * rp.dh * 4 + kGuard, kPixelAlign); }
 
@@ -1108,6 +1292,28 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
     // per atlas: (entry, plan) of the cutouts this call runs through the marching resample kernel
     std::vector<std::vector<std::pair<int, size_t>>> planar_need((size_t)std::max(n_atlases, 1));
 
+    {   // the axis tables of this call's resized boxes that the context has not seen yet, built ahead on several threads
+        std::vector<CoefKey> need;
+        std::map<CoefKey, int> listed;
+        for (int ji = 0; ji < n_jobs; ++ji) {
+            const mic_job &J = jobs[ji];
+            if (J.n_placements <= 0 || !J.placements) continue;
+            for (int pi = 0; pi < J.n_placements; ++pi) {
+                const mic_placement &Pl = J.placements[pi];
+                if (Pl.atlas < 0 || Pl.atlas >= n_atlases) continue;  // (reported by the loop below)
+                const mic_atlas *A = atlases[Pl.atlas];
+                auto it = A->index.find(Pl.object_id);
+                if (it == A->index.end()) continue;
+                const BlobEntry &E = A->entries[it->second];
+                const int64_t w = std::max<int64_t>(1, (int64_t)Pl.box[2] - Pl.box[0]), h = std::max<int64_t>(1, (int64_t)Pl.box[3] - Pl.box[1]);
+                if ((w == E.w && h == E.h) || w > kMaxDim || h > kMaxDim) continue;
+                const CoefKey kx{E.w, (int)w, E.w == (int)w ? -1 : filter, 0}, ky{E.h, (int)h, E.h == (int)h ? -1 : filter, 0};
+                for (const CoefKey &k : {kx, ky})
+                    if (!ctx->frags.count(k) && listed.emplace(k, 1).second) need.push_back(k);
+            }
+        }
+        prebuild_axis_frags(ctx, need, stream);
+    }
     for (int ji = 0; ji < n_jobs; ++ji) {
         const mic_job &J = jobs[ji];
         if (J.width <= 0 || J.height <= 0 || J.width > kMaxDim || J.height > kMaxDim)

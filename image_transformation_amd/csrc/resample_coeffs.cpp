@@ -74,13 +74,12 @@ AxisTable identity_axis_table(int size) {
     return t;
 }
 
-AxisFrags build_axis_frags(const AxisTable &t) {
-    AxisFrags f;
-    f.tiles = (t.out_size + 15) / 16;
-    f.meta.assign(static_cast<size_t>(f.tiles) * 4, 0);
-    f.bias.assign(static_cast<size_t>(f.tiles) * 16, 0);
+size_t axis_frags_layout(const AxisTable &t, AxisFrags *f) {
+    f->tiles = (t.out_size + 15) / 16;
+    f->max_chunks = 0;
+    f->meta.assign(static_cast<size_t>(f->tiles) * 4, 0);
     size_t chunks = 0;
-    for (int tile = 0; tile < f.tiles; ++tile) {
+    for (int tile = 0; tile < f->tiles; ++tile) {
         const int o0 = tile * 16, o1 = std::min(t.out_size, o0 + 16);
         int lo = t.bounds[2 * o0], hi = lo;
         for (int o = o0; o < o1; ++o) {
@@ -89,12 +88,23 @@ AxisFrags build_axis_frags(const AxisTable &t) {
         }
         const int ws = lo & ~15;
         const int n_chunks = std::max(1, (hi - ws + 63) / 64);
-        f.meta[4 * tile + 0] = ws;
-        f.meta[4 * tile + 1] = n_chunks;
-        f.meta[4 * tile + 2] = static_cast<int32_t>(chunks);
-        f.meta[4 * tile + 3] = hi;
-        f.max_chunks = std::max(f.max_chunks, n_chunks);
-        f.frags.resize((chunks + n_chunks) * 3 * 64 * 16, 0);
+        f->meta[4 * tile + 0] = ws;
+        f->meta[4 * tile + 1] = n_chunks;
+        f->meta[4 * tile + 2] = static_cast<int32_t>(chunks);
+        f->meta[4 * tile + 3] = hi;
+        f->max_chunks = std::max(f->max_chunks, n_chunks);
+        chunks += (size_t)n_chunks;
+    }
+    return chunks;
+}
+
+void fill_axis_frags(const AxisTable &t, const AxisFrags &f, int32_t *bias, int8_t *frags, size_t chunks_total) {
+    std::fill(bias, bias + static_cast<size_t>(f.tiles) * 16, 0);
+    std::fill(frags, frags + chunks_total * 3 * 64 * 16, 0);
+    for (int tile = 0; tile < f.tiles; ++tile) {
+        const int o0 = tile * 16, o1 = std::min(t.out_size, o0 + 16);
+        const int ws = f.meta[4 * tile + 0];
+        const size_t chunks = (size_t)f.meta[4 * tile + 2];  // (this tile's first chunk)
         for (int o = o0; o < o1; ++o) {
             const int first = t.bounds[2 * o], n = t.bounds[2 * o + 1];
             const int32_t *row = &t.coeffs[static_cast<size_t>(o) * t.ksize];
@@ -109,15 +119,22 @@ AxisFrags build_axis_frags(const AxisTable &t) {
                 const int pos = first + k - ws;     // window position of this tap
                 const int chunk = pos / 64, h = (pos % 64) / 16, j = pos % 16;
                 const int lane = 16 * h + (o - o0);
-                int8_t *base = &f.frags[((chunks + chunk) * 3 * 64 + lane) * 16 + j];
+                int8_t *base = &frags[((chunks + chunk) * 3 * 64 + lane) * 16 + j];
                 base[0 * 64 * 16] = static_cast<int8_t>(d0);
                 base[1 * 64 * 16] = static_cast<int8_t>(d1);
                 base[2 * 64 * 16] = static_cast<int8_t>(d2);
             }
-            f.bias[o] = static_cast<int32_t>((1 << 21) + 128 * sum);
+            bias[o] = static_cast<int32_t>((1 << 21) + 128 * sum);
         }
-        chunks += n_chunks;
     }
+}
+
+AxisFrags build_axis_frags(const AxisTable &t) {
+    AxisFrags f;
+    const size_t chunks = axis_frags_layout(t, &f);
+    f.bias.resize(static_cast<size_t>(f.tiles) * 16);
+    f.frags.resize(chunks * 3 * 64 * 16);
+    fill_axis_frags(t, f, f.bias.data(), f.frags.data(), chunks);
     return f;
 }
 

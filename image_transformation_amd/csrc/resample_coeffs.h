@@ -1,5 +1,6 @@
 // Host-side tables for one resample axis (see resample_coeffs.cpp).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -32,6 +33,11 @@ struct AxisFrags {
     std::vector<int8_t> frags;
 };
 AxisFrags build_axis_frags(const AxisTable &t);
+// The same in two steps, for callers that place the fragments themselves (several axes into one upload buffer):
+// axis_frags_layout fills tiles / max_chunks / meta and returns the number of 64-tap chunks (frags = chunks * 3072 bytes);
+// fill_axis_frags writes bias[tiles * 16] and frags[chunks * 3072] (which it zeroes first) for that layout.
+size_t axis_frags_layout(const AxisTable &t, AxisFrags *layout);
+void fill_axis_frags(const AxisTable &t, const AxisFrags &layout, int32_t *bias, int8_t *frags, size_t chunks);
 std::vector<int32_t> transpose_coeffs(const AxisTable &t);  // -> [ksize][out_size]
 void thumbnail_size(int w, int h, int req_w, int req_h, int *out_w, int *out_h);
 
