@@ -106,6 +106,8 @@ SYMBOLS = {
     "mic_render": (ctypes.c_int, [_P, _P, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, _P,
                                   ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, _P, _P, _I32P]),
     "mic_render_job": (ctypes.c_int, [_P, _P, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(Job), ctypes.c_int, _P, _I32P]),
+    "mic_render_batch": (ctypes.c_int, [_P, _P, ctypes.c_int32, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_size_t),
+                                        ctypes.POINTER(Job), ctypes.c_int, _P, _I32P]),
     "mic_thumbnail_size": (ctypes.c_int, [ctypes.c_int32] * 4 + [_I32P, _I32P]),
     "mic_contact_sheet_size": (ctypes.c_int, [ctypes.c_int32] * 5 + [_I32P, _I32P]),
     "mic_contact_sheet": (ctypes.c_int, [_P, _P, ctypes.c_int32, _I32P, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,

@@ -589,7 +589,29 @@ def coerce_placements(known_ids, placements: Iterable[Mapping]) -> List[Tuple[in
 _I32_MIN, _I32_MAX = -(2 ** 31), 2 ** 31 - 1
 
 
+_PLACEMENT_DTYPE = np.dtype([("atlas", np.int32), ("object_id", np.int32), ("box", np.int32, (4,))])
+assert _PLACEMENT_DTYPE.itemsize == ctypes.sizeof(Placement)
+
+
 def _fill_placements(rows: Sequence[Tuple[int, int, int, int, int]], atlas_index: int = 0):
+    """Coerced rows -> an array of mic_placement (a ctypes array for a handful of rows, a NumPy structured array of
+    the same layout for long lists: 512 placements of a 16-canvas batch are one vectorised conversion instead of 512
+    trips through ctypes attribute setters)."""
+    n = len(rows)
+    if n >= 16:
+        try:
+            a = np.asarray(rows, dtype=np.int64)
+        except OverflowError:
+            raise OverflowError("placement coordinates do not fit 32 bits") from None
+        if a.shape != (n, 5):
+            raise ValueError("placement rows are (object_id, x1, y1, x2, y2)")
+        if (a < _I32_MIN).any() or (a > _I32_MAX).any():
+            raise OverflowError("placement coordinates do not fit 32 bits")
+        arr = np.empty(n, _PLACEMENT_DTYPE)
+        arr["atlas"] = atlas_index
+        arr["object_id"] = a[:, 0]
+        arr["box"] = a[:, 1:5]
+        return arr
     arr = (Placement * max(len(rows), 1))()
     for i, (oid, x1, y1, x2, y2) in enumerate(rows):
         if not (_I32_MIN <= x1 <= _I32_MAX and _I32_MIN <= y1 <= _I32_MAX and
@@ -657,7 +679,8 @@ def _make_job(size, bg_dev_ptr, bg_rgba, placement_arr, n_place, out_ptr) -> Job
         for k in range(4):
             j.bg_rgba[k] = bg_rgba[k]
     j.n_placements = n_place
-    j.placements = ctypes.cast(placement_arr, ctypes.POINTER(Placement))
+    j.placements = ctypes.cast(placement_arr.ctypes.data if isinstance(placement_arr, np.ndarray) else placement_arr,
+                               ctypes.POINTER(Placement))
     j.out_dev = out_ptr
     return j
 
@@ -1090,5 +1113,75 @@ def render_batch(layouts: Sequence[Any], objects: Mapping[int, Any], canvases: S
     """One launch for a batch of variants of one bundle (BASELINE.json configs[3]): layouts[i] onto
     canvases[i].  Returns device tensors; nothing is copied to the host."""
     atlas = _as_atlas(objects)
+    canvases = list(canvases)
+    if len(layouts) != len(canvases):
+        raise ValueError("one layout per canvas")
+    got = _render_batch_native(layouts, atlas, canvases, outs, filter)
+    if got is not None:
+        return got
     rows = [_layout_rows(layout, atlas, atlas, _canvas_size(cv)) for layout, cv in zip(layouts, canvases)]
-    return composite_device(atlas, list(canvases), rows, outs=outs, filter=filter)
+    return composite_device(atlas, canvases, rows, outs=outs, filter=filter)
+
+
+def _render_batch_native(layouts, atlas: "Atlas", canvases, outs, filter: int):
+    """mic_render_batch: every Flex tree (JSON text, or a {"root": ...} dict serialised here) placed and composited
+    inside libmic -- no placement passes through Python objects.  None: some layout is not a Flex tree, or the native
+    placer leaves one of them to flex.py (the caller then takes the per-layout path, which also raises the reference's
+    errors for malformed trees)."""
+    n = len(layouts)
+    if n == 0:
+        return None
+    texts = []
+    for lay in layouts:
+        if isinstance(lay, bytes):
+            texts.append(lay)
+        elif isinstance(lay, str):
+            texts.append(lay.encode("utf-8"))
+        elif isinstance(lay, dict) and "root" in lay:
+            try:
+                texts.append(json.dumps(lay, separators=(",", ":")).encode("utf-8"))
+            except (TypeError, ValueError):
+                return None
+        else:
+            return None
+    if filter not in _FILTERS:
+        raise ValueError(f"unknown filter {filter}")
+    torch = _torch()
+    ctx = atlas.ctx
+    jobs = (Job * n)()
+    keep = []
+    sizes = []
+    for i, cv in enumerate(canvases):
+        j = jobs[i]
+        if isinstance(cv, SolidCanvas):
+            W, H = cv.size
+            cv._job_colour(j)
+        else:
+            if cv.dtype != torch.uint8 or cv.dim() != 3 or cv.shape[2] != 4 or not cv.is_contiguous():
+                raise ValueError("device canvas must be a contiguous uint8 (H, W, 4) tensor")
+            if cv.device != ctx.torch_device:
+                raise ValueError("canvas lives on another device than the atlas")
+            H, W = int(cv.shape[0]), int(cv.shape[1])
+            j.bg_dev, j.bg_rgba_dev = cv.data_ptr(), None
+        keep.append(cv)
+        j.width, j.height, j.n_placements = W, H, 0
+        sizes.append((W, H))
+    if outs is None:
+        outs = [torch.empty((H, W, 4), dtype=torch.uint8, device=ctx.torch_device) for (W, H) in sizes]
+    if len(outs) != n:
+        raise ValueError("one output canvas per job")
+    for i, out in enumerate(outs):
+        W, H = sizes[i]
+        if tuple(out.shape) != (H, W, 4) or out.dtype != torch.uint8 or not out.is_contiguous() or out.device != ctx.torch_device:
+            raise ValueError("output canvas has the wrong shape/dtype/device")
+        jobs[i].out_dev = out.data_ptr()
+    tarr = (ctypes.c_char_p * n)(*texts)
+    lens = (ctypes.c_size_t * n)(*[len(t) for t in texts])
+    atlas.wait_ready()
+    with _device_guard(ctx):
+        rc = _native.lib().mic_render_batch(ctx.handle, atlas.handle, n, tarr, lens, jobs, filter, _P(ctx.stream_ptr()), None)
+    del keep
+    if rc in (_native.ERR_UNSUPPORTED, _native.ERR_FORMAT):
+        return None
+    _native.check(rc)
+    return list(outs)

@@ -57,7 +57,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 
 extern "C" const char *mic_last_error(void) { return g_err; }
-extern "C" int mic_version(void) { return (1 << 16) | 9; }  // 1.9: + mic_plan_invalidate, mic_layer_cache_clear, mic_stats.cached_layers (resident resampled layers), mic_job.bg_rgba_dev, mic_render_job, mic_png_info / _decode(_rows, _many, _counts); 1.8: + mic_png_write_async / mic_png_wait; 1.7: + mic_median_rgb_batch, mic_host_rows_solid, mic_download(_wait); 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
+extern "C" int mic_version(void) { return (1 << 16) | 9; }  // 1.9: + mic_plan_invalidate, mic_layer_cache_clear, mic_stats.cached_layers (resident resampled layers), mic_job.bg_rgba_dev, mic_render_job, mic_render_batch, mic_png_info / _decode(_rows, _many, _counts); 1.8: + mic_png_write_async / mic_png_wait; 1.7: + mic_median_rgb_batch, mic_host_rows_solid, mic_download(_wait); 1.6: + mic_png_* (1.5: + mic_stats.marched_layers; 1.4: + mic_contact_sheet(_size); thread-safe contexts)
 
 // ------------------------------------------------------------------------------------ blob layout
 namespace {
@@ -1702,42 +1702,60 @@ extern "C" int mic_render(mic_ctx *ctx, mic_atlas *atlas, const char *layout_jso
     return mic_render_job(ctx, atlas, layout_json, len, &canvas, filter, stream_v, n_placed);
 }
 
-extern "C" int mic_render_job(mic_ctx *ctx, mic_atlas *atlas, const char *layout_json, size_t len, const mic_job *canvas,
-                              int filter, void *stream_v, int32_t *n_placed) {
-    CTX_ENTER(ctx);
-    if (!canvas) return fail(MIC_ERR_INVALID, "mic_render: bad arguments");
-    const int32_t width = canvas->width, height = canvas->height;
-    if (!atlas || !layout_json || !canvas->out_dev || width <= 0 || height <= 0)
-        return fail(MIC_ERR_INVALID, "mic_render: bad arguments");
-    if (atlas->ctx != ctx) return fail(MIC_ERR_INVALID, "mic_render: atlas belongs to another context");
-    // the sizes the placer sees: one entry per id, the first occurrence (what a dict would hold)
+// The sizes the placer sees of an atlas: one entry per id, the first occurrence (what a dict would hold).
+static void placer_table(const mic_atlas *atlas, std::vector<int32_t> *ids, std::vector<int32_t> *ws, std::vector<int32_t> *hs) {
     const size_t n = atlas->index.size();
-    std::vector<int32_t> ids, ws, hs;
-    ids.reserve(n); ws.reserve(n); hs.reserve(n);
+    ids->reserve(n); ws->reserve(n); hs->reserve(n);
     for (size_t i = 0; i < atlas->entries.size(); ++i) {
         const BlobEntry &e = atlas->entries[i];
         if (atlas->index.at(e.id) != (int)i) continue;
-        ids.push_back(e.id); ws.push_back(e.w); hs.push_back(e.h);
+        ids->push_back(e.id); ws->push_back(e.w); hs->push_back(e.h);
     }
+}
+
+extern "C" int mic_render_job(mic_ctx *ctx, mic_atlas *atlas, const char *layout_json, size_t len, const mic_job *canvas,
+                              int filter, void *stream_v, int32_t *n_placed) {
+    const char *layouts[1] = {layout_json};
+    const size_t lens[1] = {len};
+    return mic_render_batch(ctx, atlas, 1, layouts, lens, canvas, filter, stream_v, n_placed);
+}
+
+extern "C" int mic_render_batch(mic_ctx *ctx, mic_atlas *atlas, int32_t n, const char *const *layouts, const size_t *lens,
+                                const mic_job *canvases, int filter, void *stream_v, int32_t *n_placed) {
+    CTX_ENTER(ctx);
+    if (n < 0 || (n > 0 && (!layouts || !lens || !canvases)) || !atlas) return fail(MIC_ERR_INVALID, "mic_render: bad arguments");
+    if (atlas->ctx != ctx) return fail(MIC_ERR_INVALID, "mic_render: atlas belongs to another context");
+    std::vector<int32_t> ids, ws, hs;
+    placer_table(atlas, &ids, &ws, &hs);
+    // every tree is placed before anything is launched: one that needs the Python mirror declines the whole call
+    std::vector<std::vector<mic_placement>> pls((size_t)n);
+    std::vector<mic_job> jobs((size_t)n);
     std::vector<int32_t> oi, ob;
     std::string err;
-    const int frc = flex_place(layout_json, len, (int)ids.size(), ids.data(), ws.data(), hs.data(), width, height, &oi,
-                               &ob, &err);
-    if (frc == kFlexMalformed) return fail(MIC_ERR_FORMAT, "mic_render: %s", err.c_str());
-    if (frc == kFlexUnsupported)
-        return fail(MIC_ERR_UNSUPPORTED, "mic_render: layout uses features only the Python placer mirrors");
-    if (n_placed) *n_placed = (int32_t)oi.size();
-    std::vector<mic_placement> pl(oi.size());
-    for (size_t i = 0; i < oi.size(); ++i) {
-        pl[i].atlas = 0;
-        pl[i].object_id = oi[i];
-        for (int k = 0; k < 4; ++k) pl[i].box[k] = ob[4 * i + k];
+    for (int32_t k = 0; k < n; ++k) {
+        const mic_job &cv = canvases[k];
+        if (!layouts[k] || !cv.out_dev || cv.width <= 0 || cv.height <= 0) return fail(MIC_ERR_INVALID, "mic_render: layout %d: bad arguments", k);
+        oi.clear();
+        ob.clear();
+        const int frc = flex_place(layouts[k], lens[k], (int)ids.size(), ids.data(), ws.data(), hs.data(), cv.width, cv.height, &oi,
+                                   &ob, &err);
+        if (frc == kFlexMalformed) return fail(MIC_ERR_FORMAT, "mic_render: layout %d: %s", k, err.c_str());
+        if (frc == kFlexUnsupported)
+            return fail(MIC_ERR_UNSUPPORTED, "mic_render: layout %d uses features only the Python placer mirrors", k);
+        if (n_placed) n_placed[k] = (int32_t)oi.size();
+        std::vector<mic_placement> &pl = pls[(size_t)k];
+        pl.resize(oi.size());
+        for (size_t i = 0; i < oi.size(); ++i) {
+            pl[i].atlas = 0;
+            pl[i].object_id = oi[i];
+            for (int c = 0; c < 4; ++c) pl[i].box[c] = ob[4 * i + c];
+        }
+        jobs[(size_t)k] = cv;
+        jobs[(size_t)k].n_placements = (int32_t)pl.size();
+        jobs[(size_t)k].placements = pl.data();
     }
-    mic_job job = *canvas;
-    job.n_placements = (int32_t)pl.size();
-    job.placements = pl.data();
     mic_atlas *atl[1] = {atlas};
-    return mic_composite_batch(ctx, 1, atl, 1, &job, filter, stream_v);
+    return mic_composite_batch(ctx, 1, atl, n, jobs.data(), filter, stream_v);
 }
 
 extern "C" int mic_contact_sheet_size(int32_t n, int32_t thumb_w, int32_t thumb_h, int32_t cols, int32_t label_h,

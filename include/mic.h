@@ -309,6 +309,13 @@ int mic_render(mic_ctx *ctx, mic_atlas *atlas, const char *layout_json, size_t l
  * taken from *canvas, its placement fields are ignored (the Flex tree provides the placements).                   */
 int mic_render_job(mic_ctx *ctx, mic_atlas *atlas, const char *layout_json, size_t len, const mic_job *canvas,
                    int filter, void *stream, int32_t *n_placed);
+/* (1.9) n Flex trees onto n canvases in ONE call and one composite launch per kernel class -- a batch of aspect-ratio
+ * variants of one bundle (BASELINE configs[3]; the reference runs run_macro_only once per ratio): layouts[i] (lens[i]
+ * bytes of JSON text) is placed over canvases[i] and composited into its out_dev.  Every tree is placed before anything
+ * is launched: MIC_ERR_UNSUPPORTED / MIC_ERR_FORMAT name the first tree the native placer leaves to the caller or cannot
+ * parse, and nothing has been enqueued then.  n_placed (optional): n counts.                                         */
+int mic_render_batch(mic_ctx *ctx, mic_atlas *atlas, int32_t n, const char *const *layouts, const size_t *lens,
+                     const mic_job *canvases, int filter, void *stream, int32_t *n_placed);
 
 /* ---- helpers ----------------------------------------------------------------------------- */
 /* Pillow Image.thumbnail size rule (macro_placement_test.py:194). */

@@ -396,3 +396,78 @@ def test_selftest_canary(abi):
     agrees with host arithmetic on this compiler build."""
     lib, ctx = abi[0], abi[1]
     assert lib.mic_selftest(ctx, _stream()) == 0, lib.mic_last_error()
+
+
+def test_raw_abi_render_batch(abi):
+    """mic_render_batch (1.9): n Flex trees onto n canvases in one call -- different sizes, a solid colour on the host, one
+    in device memory, a background image -- against flex.py + the oracle; a tree the native placer declines makes the
+    whole call return MIC_ERR_UNSUPPORTED with nothing enqueued; the Python render_batch() falls back per layout then."""
+    import json
+    import torch
+    from image_transformation_amd import flex
+    from image_transformation_amd.compositor import Atlas, SolidCanvas, render_batch
+    lib, ctx, nat = abi
+    rng = np.random.default_rng(515)
+    objs = {i + 1: cases.synthetic.make_cutout(rng, int(rng.integers(20, 90)), int(rng.integers(15, 60)), "soft") for i in range(6)}
+    atlas = _make_atlas(lib, ctx, objs)
+    sizes = {k: (v.shape[1], v.shape[0]) for k, v in objs.items()}
+    dims = [(333, 211), (640, 200), (256, 256)]
+    layouts = [{"root": {"type": "flex", "direction": d, "gap_px": g, "justify": j, "align": a,
+                         "children": [{"object_id": k} for k in order]}}
+               for d, g, j, a, order in (("row", 4, "center", "end", [1, 2, 3]), ("row", 0, "space_between", "start", [6, 5, 4, 3, 2, 1]),
+                                         ("column", 7, "space_around", "center", [2, "4", 99, 6]))]
+    texts = [json.dumps(l).encode() for l in layouts]
+    word = torch.tensor((9, 8, 7, 255), dtype=torch.uint8, device="cuda")
+    bg_img = rng.integers(0, 256, (dims[2][1], dims[2][0], 4), dtype=np.uint8)
+    bg_dev = torch.from_numpy(bg_img).cuda()
+    jobs = (nat.Job * 3)()
+    outs, bgs = [], []
+    for i, (W, H) in enumerate(dims):
+        out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        outs.append(out)
+        jobs[i].width, jobs[i].height, jobs[i].out_dev = W, H, out.data_ptr()
+        b = np.empty((H, W, 4), np.uint8)
+        if i == 0:
+            for c, v in enumerate((200, 100, 50, 255)):
+                jobs[i].bg_rgba[c] = v
+            b[:] = (200, 100, 50, 255)
+        elif i == 1:
+            jobs[i].bg_rgba_dev = word.data_ptr()
+            b[:] = (9, 8, 7, 255)
+        else:
+            jobs[i].bg_dev = bg_dev.data_ptr()
+            b = bg_img
+        bgs.append(b)
+    tarr = (ctypes.c_char_p * 3)(*texts)
+    lens = (ctypes.c_size_t * 3)(*[len(t) for t in texts])
+    placed = (ctypes.c_int32 * 3)()
+    assert lib.mic_render_batch(ctx, atlas, 3, tarr, lens, jobs, 0, _stream(), placed) == 0, lib.mic_last_error()
+    for i, (W, H) in enumerate(dims):
+        pl = flex.layout_to_placements(layouts[i], sizes, (W, H))
+        assert placed[i] == len(pl)
+        assert np.array_equal(outs[i].cpu().numpy(), oracle.composite(bgs[i], objs, pl)), i
+    # one tree the native placer leaves to the Python mirror: the whole call declines, nothing is written
+    # (int("1_0") == 10 in Python: a gap the reference accepts and the native placer leaves to the mirror)
+    odd_tree = {"root": {"type": "flex", "direction": "row", "gap_px": "1_0", "children": [{"object_id": 1}, {"object_id": 2}]}}
+    odd = json.dumps(odd_tree).encode()
+    rc_one = lib.mic_render_job(ctx, atlas, odd, len(odd), ctypes.byref(jobs[0]), 0, _stream(), None)
+    assert rc_one == nat.ERR_UNSUPPORTED, rc_one
+    if rc_one == nat.ERR_UNSUPPORTED:
+        for o in outs:
+            o.zero_()
+        tarr2 = (ctypes.c_char_p * 3)(texts[0], odd, texts[2])
+        lens2 = (ctypes.c_size_t * 3)(len(texts[0]), len(odd), len(texts[2]))
+        assert lib.mic_render_batch(ctx, atlas, 3, tarr2, lens2, jobs, 0, _stream(), None) == nat.ERR_UNSUPPORTED
+        torch.cuda.synchronize()
+        assert not any(bool(o.any()) for o in outs)
+    assert lib.mic_render_batch(ctx, atlas, 3, (ctypes.c_char_p * 3)(texts[0], b"{nope", texts[2]), lens, jobs, 0, _stream(), None) == nat.ERR_FORMAT
+    assert lib.mic_atlas_destroy(atlas) == 0
+    # the package's render_batch: JSON texts, dicts and a layout that needs the Python mirror (pin) in one batch
+    a2 = Atlas(objs)
+    mixed = [texts[0].decode(), layouts[1], odd_tree]
+    cvs = [SolidCanvas(dims[0], (200, 100, 50, 255)), SolidCanvas(dims[1], colour_dev=word), bg_dev]
+    got = render_batch(mixed, a2, cvs)
+    for i, (W, H) in enumerate(dims):
+        lay = json.loads(mixed[i]) if isinstance(mixed[i], str) else mixed[i]
+        pl = flex.layout_to_placements(lay, sizes, (W, H))
+        assert np.array_equal(got[i].cpu().numpy(), oracle.composite(bgs[i], objs, pl)), ("render_batch", i)
