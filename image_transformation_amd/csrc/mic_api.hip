@@ -1783,29 +1783,49 @@ extern "C" int mic_contact_sheet(mic_ctx *ctx, mic_atlas *atlas, int32_t n, cons
     if (atlas->ctx != ctx) return fail(MIC_ERR_INVALID, "mic_contact_sheet: atlas belongs to another context");
     const int cell_w = thumb_w, cell_h = thumb_h + label_h;
     // the labels become a throw-away atlas of black RGBA strips whose alpha is the coverage mask: blending one
-    // with the alpha-over kernel is ImageDraw.text's own mask blend on an opaque sheet, div255(dst * (255 - m) + 128)
-    std::vector<std::vector<uint8_t>> rgba((size_t)n_strips);
+    // with the alpha-over kernel is ImageDraw.text's own mask blend on an opaque sheet, div255(dst * (255 - m) + 128).
+    // The strips travel through a slot of the staging ring (pinned host half -> device half, one asynchronous copy) and
+    // are wrapped by a non-owning atlas on this stack frame: no allocation, no device-wide wait (round 4; it used to be
+    // an atlas of its own: hipMalloc + a synchronous copy + hipDeviceSynchronize + hipFree per sheet).
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (int rc = adopt_stream(ctx, stream)) return rc;
     std::vector<int32_t> sid((size_t)n_strips), sw((size_t)n_strips), sh((size_t)n_strips);
-    std::vector<const uint8_t *> sp((size_t)n_strips);
     for (int k = 0; k < n_strips; ++k) {
         const mic_label_strip &S = strips[k];
         if (S.w <= 0 || S.h <= 0 || !S.coverage_host || S.cell < 0 || S.cell >= n)
             return fail(MIC_ERR_INVALID, "mic_contact_sheet: label strip %d is malformed", k);
         if ((int64_t)S.w * S.h > kMaxLayerPx) return fail(MIC_ERR_INVALID, "mic_contact_sheet: label strip %d is too large", k);
-        rgba[(size_t)k].assign((size_t)S.w * S.h * 4, 0);
-        for (size_t i = 0; i < (size_t)S.w * S.h; ++i) rgba[(size_t)k][4 * i + 3] = S.coverage_host[i];
-        sid[(size_t)k] = k; sw[(size_t)k] = S.w; sh[(size_t)k] = S.h; sp[(size_t)k] = rgba[(size_t)k].data();
+        sid[(size_t)k] = k; sw[(size_t)k] = S.w; sh[(size_t)k] = S.h;
     }
+    mic_atlas labels_obj;
     mic_atlas *labels = nullptr;
-    if (n_strips > 0)
-        if (int rc = mic_atlas_create(ctx, n_strips, sid.data(), sw.data(), sh.data(), sp.data(), &labels)) return rc;
+    if (n_strips > 0) {
+        size_t total = 0;
+        if (int rc = blob_layout(n_strips, sid.data(), sw.data(), sh.data(), &labels_obj.entries, &total)) return rc;
+        Slot *slot = nullptr;
+        if (int rc = acquire_slot(ctx, total, &slot)) return rc;
+        uint8_t *hp = static_cast<uint8_t *>(slot->host);
+        memset(hp, 0, total);  // (guard bands, gaps and the strips' r, g, b)
+        for (int k = 0; k < n_strips; ++k) {
+            const mic_label_strip &S = strips[k];
+            uint8_t *px = hp + labels_obj.entries[(size_t)k].offset;
+            for (size_t i = 0; i < (size_t)S.w * S.h; ++i) px[4 * i + 3] = S.coverage_host[i];
+        }
+        HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, total, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipEventRecord(slot->ev, stream));
+        slot->pending = true;
+        labels_obj.ctx = ctx;
+        labels_obj.blob = slot->dev;  // (read by this call's composite launch, which follows on the same stream)
+        labels_obj.bytes = total;
+        labels_obj.owns = false;
+        atlas_finish(&labels_obj);
+        labels = &labels_obj;
+    }
     std::vector<mic_placement> pl;
     for (int i = 0; i < n; ++i) {
         auto it = atlas->index.find(object_ids[i]);
-        if (it == atlas->index.end()) {
-            mic_atlas_destroy(labels);
+        if (it == atlas->index.end())
             return fail(MIC_ERR_INVALID, "mic_contact_sheet: object id %d is not in the atlas", object_ids[i]);
-        }
         const BlobEntry &E = atlas->entries[(size_t)it->second];
         int tw = 0, th = 0;
         thumbnail_size(E.w, E.h, thumb_w, thumb_h, &tw, &th);
@@ -1824,9 +1844,7 @@ extern "C" int mic_contact_sheet(mic_ctx *ctx, mic_atlas *atlas, int32_t n, cons
     job.placements = pl.data();
     job.out_dev = out_dev;
     mic_atlas *atl[2] = {atlas, labels};
-    int rc = mic_composite_batch(ctx, labels ? 2 : 1, atl, 1, &job, MIC_FILTER_LANCZOS, stream_v);
-    mic_atlas_destroy(labels);  // waits for the device: the launch has read the strips by then
-    return rc;
+    return mic_composite_batch(ctx, labels ? 2 : 1, atl, 1, &job, MIC_FILTER_LANCZOS, stream_v);
 }
 
 extern "C" int mic_plan_create(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, int n_jobs,
