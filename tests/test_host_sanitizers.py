@@ -143,3 +143,22 @@ def test_png_huffman_codes_are_complete_and_limited(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([out], capture_output=True, timeout=900, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert r.returncode == 0 and r.stdout.strip() == b"bad=0 monotonic_violations=0", (r.stdout, r.stderr[-2000:])
+
+
+def test_host_pool_under_tsan(tmp_path):
+    """csrc/host_pool.h (the parked threads that build a call's axis tables) under ThreadSanitizer: four caller threads
+    run 1 200 loops of 1-97 parts on the one pool at once; every part runs exactly once, a throwing part makes run()
+    return false, no race is reported."""
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "host_pool_tsan")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-I", CSRC, os.path.join(ROOT, "tests", "native", "host_pool_main.cpp"),
+           "-lpthread", "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "tsan" in (r.stderr or "").lower() and "cannot find" in r.stderr.lower():
+        pytest.skip("libtsan not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    assert b"ThreadSanitizer" not in r.stderr and b"data race" not in r.stderr, r.stderr[-3000:]
+    assert r.stdout.strip().endswith(b"bad=0") and b"loops=1200" in r.stdout, r.stdout
