@@ -9,21 +9,23 @@
 // ONE launch.  Every pixel goes into one of two histogram sets, keyed by alpha > 0 / alpha == 0.
 // The reference's "all pixels" fallback only triggers when no pixel has alpha > 0 -- and then the
 // alpha == 0 set IS all pixels -- so the two sets answer both cases from a single pass.  The block
-// that retires last (device-scope ticket) runs the 256-bin scan + select and then re-zeroes the
-// scratch, so the next call needs neither a memset nor a second kernel.
+// that retires last (device-scope ticket) runs the 256-bin scan + select; the scratch is a double
+// buffer that the NEXT call clears, so no call needs a memset or a second kernel.
 //
-// Shape: at most 512 blocks of 16 waves (two per CU fill every wave slot of the chip), one LDS
-// histogram per block (8 bank-interleaved replicas, 48 KiB).  A wave owns 4 KiB of the image per trip and issues its four 16-byte
-// loads per lane back to back, unconditionally (a load under a branch makes hipcc wait for it
-// before issuing the next); only the single ragged trip at the end of the image goes through a
-// guarded per-pixel path.  Few, large blocks also keep the two per-block costs small: the flush of
-// non-empty bins (same-address global atomics from every block) and the agent-scope release on the
-// ticket.
+// Shape: at most 256 blocks of 16 waves (one per CU), one LDS histogram per block (16 bank-interleaved
+// replicas, 96 KiB).  A wave owns 4 KiB of the image per trip and issues its four 16-byte loads per
+// lane back to back, unconditionally (a load under a branch makes hipcc wait for it before issuing
+// the next); only the single ragged trip at the end of the image goes through a guarded per-pixel
+// path.  Few, large blocks also keep the per-block costs small: the flush of non-empty bins
+// (same-address global atomics from every block) and the ticket.
 //
-// Backgrounds are mostly flat, so within a wave all 256 pixels of a chunk often hit the same bin;
-// instead of letting 256 same-address LDS atomics serialise, the wave tests each channel for that
-// case with readfirstlane/__ballot and lets one lane add the population count.  Otherwise (noisy
-// regions, mostly distinct bins) every lane issues its own LDS atomics.
+// Per pixel the loop is three LDS atomics and their addresses, plus one test per chunk of 256 pixels
+// for "all one colour" (then lane 0 adds 256 to three bins).  Rounds 1-3 tested every chunk for
+// "flat" lanes per channel (backgrounds are mostly flat, and 64 same-address LDS atomics serialise)
+// and kept the pixel counts of both sets in registers: ~190 instructions per chunk, four waves per
+// SIMD -- the kernel was bound by issuing them, not by memory or by the LDS
+// (profiles/r04_median_experiments.txt: 8K photo-like 40 -> 26 us).  With 16 replicas a chunk of
+// near-equal pixels queues 4 lanes deep per word at worst; the counts are the histograms' own totals.
 #include <algorithm>
 #include <cstdlib>
 
@@ -36,21 +38,22 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kHistWaves = 16;
 constexpr int kChunks = 4;                      // 16-byte loads a lane keeps in flight per trip
 constexpr size_t kTripPx = (size_t)256 * kChunks;  // pixels one wave takes per trip (4 KiB)
+constexpr uint64_t kTwoLaunchPx = 6ull << 20;  // images from here up take the two-launch form (see launch_median_batch)
 constexpr unsigned kMaxBlocks = 256;  // one block of 16 waves per CU (round 3 sweep: 512 -> 256: 4K 17.2 -> 16.3 us, 8K 32.2 -> 31.3; 384 / 320 / 192 leave CUs unevenly loaded: 8K 36-41 us)
 // LDS histogram replicas, interleaved so the kCopies words of one bin sit in kCopies different banks:
 // word = bin_index * kCopies + (lane & (kCopies - 1)).  64 lanes hitting one bin serialise 64/kCopies
-// deep instead of 64.
-constexpr int kCopies = 8;
+// deep instead of 64 (round 4: 8 -> 16 replicas, 96 KiB).
+constexpr int kCopies = 16;
 
-// scratch layout of one image's slot (uint32): kGlobalCopies x { [set][channel][256], counts[2] } (set 0 = alpha > 0, set 1 =
-// alpha == 0), then the retirement ticket.  Zero on entry (the scratch is a double buffer: a call clears the half the
+// scratch layout of one image's slot (uint32): kGlobalCopies x { [set][channel][256] + padding } (set 0 = alpha > 0, set 1 =
+// alpha == 0), then the retirement ticket.  (No pixel counts: a set's count is the total of any of its three histograms.)  Zero on entry (the scratch is a double buffer: a call clears the half the
 // previous call used).  Block b flushes into copy b % 8 -- the
 // XCD it runs on, as workgroups are dealt round-robin -- so that a bin's same-address atomics (they execute
 // one after another at the memory side, ~12 ns each) are spread over eight addresses: a 4K image's 506
 // blocks put 63 adds on an address instead of 506.  The last block sums the copies.
 constexpr int kSetWords = 3 * 256;
-constexpr int kCountOff = 2 * kSetWords;
-constexpr int kCopyWords = kCountOff + 16;  // counts[2] + padding to a 64-byte multiple
+constexpr int kCopyWords = 2 * kSetWords + 16;  // (+ padding: the copies start in different L2 channels)
+static_assert(kCopyWords % 2 == 0, "bins are flushed in pairs, as one 64-bit atomic");
 constexpr int kGlobalCopies = 8;
 constexpr int kTicketOff = kGlobalCopies * kCopyWords;
 static_assert(kTicketOff < (int)kMedianSlotWords, "median scratch slot too small");
@@ -65,50 +68,33 @@ __device__ inline uint32_t agent_load(const uint32_t *p) {
 }
 
 // One chunk: the 4 pixels each lane of the wave holds (256 consecutive pixels per wave).  ok[] marks
-// the pixels inside the image; lane 0's p[0] is always one of them.
-//
-// Same-address LDS atomics serialise, and backgrounds are mostly flat: left alone, 256 pixels of one
-// colour cost 768 serialised adds.  The budget at HBM speed is ~120 VALU instructions and ~120 LDS
-// cycles per chunk, so the remedy has to be cheap: per channel, a lane whose 4 pixels all equal the
-// leader pixel (lane 0's first) in that channel and alpha class is "flat"; flat lanes are counted
-// with one __ballot/popcount and added once by lane 0, and only the other lanes issue LDS atomics.
-// A flat chunk costs 3 adds, flat-with-detail a few lanes' worth, noise what the plain loop costs.
+// the pixels inside the image (FULL: all of them).  Three LDS atomics per pixel into the lane's replica.
 template <bool FULL>
 __device__ inline void hist_chunk(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, bool ok0, bool ok1, bool ok2,
-                                  bool ok3, uint32_t *lh, int lane, uint32_t &n_opaque, uint32_t &n_clear) {
+                                  bool ok3, uint32_t *lh, int lane) {
     const uint32_t p[4] = {p0, p1, p2, p3};
     const bool ok[4] = {ok0, ok1, ok2, ok3};
-    const uint32_t copy = (uint32_t)lane & (kCopies - 1);
-    const uint32_t lp = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);  // the leader pixel
-    const uint32_t lset = (lp >> 24) != 0u ? 0u : 1u;
-    uint32_t cls[4];  // histogram set of each pixel: 0 = alpha > 0, 1 = alpha == 0
-    uint32_t cnt = 0, clr = 0;
-    // diff: OR of (pixel ^ leader) over the lane's pixels; bit 24 is replaced by "alpha class differs
-    // from the leader's", bits 25-31 are dropped.  A ragged chunk (!FULL) takes no shortcut.
-    uint32_t diff = FULL ? 0u : ~0u;
+    uint32_t *mine = lh + ((uint32_t)lane & (kCopies - 1));
+    if (FULL) {
+        // a chunk of ONE colour (flat backgrounds are common): lane 0 adds 256 to its three bins instead of the wave
+        // queueing four deep on 16 words.  One compare and one wave-uniform branch per chunk -- not the per-channel,
+        // per-lane test of rounds 1-3, which cost more than the conflicts it avoided.
+        const uint32_t lp = (uint32_t)__builtin_amdgcn_readfirstlane((int)p0);
+        if (__ballot(((p0 ^ lp) | (p1 ^ lp) | (p2 ^ lp) | (p3 ^ lp)) != 0u) == 0ull) {
+            if (lane == 0) {
+                uint32_t *set = lh + ((lp >> 24) != 0u ? 0 : kSetWords * kCopies);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) atomicAdd(&set[(c * 256 + ((lp >> (8 * c)) & 255u)) * kCopies], 256u);
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        cls[j] = (p[j] >> 24) != 0u ? 0u : 1u;
-        cnt += (FULL || ok[j]) ? 1u : 0u;
-        clr += (FULL || ok[j]) ? cls[j] : 0u;
-        diff |= ((p[j] ^ lp) & 0x00ffffffu) | ((cls[j] ^ lset) << 24);
-    }
-    n_opaque += cnt - clr;
-    n_clear += clr;
+        if (!(FULL || ok[j])) continue;
+        uint32_t *set = mine + ((p[j] >> 24) != 0u ? 0 : kSetWords * kCopies);  // 0 = alpha > 0, 1 = alpha == 0
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const int sh = 8 * c;
-        const bool flat = (diff & ((255u << sh) | (1u << 24))) == 0u;
-        const unsigned long long fb = __ballot(flat);
-        if (fb != 0 && lane == 0)
-            atomicAdd(&lh[((lset * 3 + c) * 256 + ((lp >> sh) & 255u)) * kCopies], 4u * (uint32_t)__popcll(fb));
-        if (fb == ~0ull) continue;  // wave-uniform: the whole chunk is flat in this channel
-        if (!flat) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (FULL || ok[j])
-                    atomicAdd(&lh[((cls[j] * 3 + c) * 256 + ((p[j] >> sh) & 255u)) * kCopies + copy], 1u);
-        }
+        for (int c = 0; c < 3; ++c) atomicAdd(&set[(c * 256 + ((p[j] >> (8 * c)) & 255u)) * kCopies], 1u);
     }
 }
 
@@ -133,38 +119,50 @@ struct MedianBatch {
 };
 
 // Last block of an image, 1024 threads: thread t carries bin (t & 255) of channel (t >> 8) (the fourth quarter
-// idles).  All global loads are issued up front -- they are agent-scope, a memory round trip each --
-// then one 256-bin scan per channel picks the order statistics (n-1)//2 and n//2 and thread 0 writes
-// int((lo + hi) / 2): np.median's mean of the two middle values, truncated by int().
+// idles).  Set 0 (alpha > 0) first: its copies are loaded together -- agent-scope loads, one memory round trip --
+// and one 256-bin scan per channel gives both the set's pixel count (the scan's total) and the order statistics
+// (n-1)//2 and n//2; only an image without a single pixel of alpha > 0 goes round again for set 1.  Thread 0
+// writes int((lo + hi) / 2): np.median's mean of the two middle values, truncated by int().
 __device__ void median_select(const uint32_t *hist, int copies, uint32_t *out_rgba, uint32_t *wave_tot,
                               uint32_t (*res)[2]) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int c = t >> 8, bin = t & 255;
     const bool act = c < 3;
-    uint32_t n0 = 0, n1 = 0, v0 = 0, v1 = 0;
+    uint32_t v = 0, incl = 0, n = 0;
+    for (int set = 0; set < 2; ++set) {
+        v = 0;
+        if (act) {
+            const uint32_t *h = hist + (set * 3 + c) * 256 + bin;
+            if (copies == kGlobalCopies) {  // (block-uniform) all eight loads in flight together: no branch between them --
+                uint32_t x[kGlobalCopies];   // a loop with an early exit made hipcc wait for every load before the next
 #pragma unroll
-    for (int g = 0; g < kGlobalCopies; ++g) {  // up to 32 loads issued together: one round trip
-        if (g >= copies) break;
-        const uint32_t *h = hist + g * kCopyWords;
-        n0 += agent_load(h + kCountOff);
-        n1 += agent_load(h + kCountOff + 1);
-        v0 += act ? agent_load(h + (0 * 3 + c) * 256 + bin) : 0u;
-        v1 += act ? agent_load(h + (1 * 3 + c) * 256 + bin) : 0u;
+                for (int g = 0; g < kGlobalCopies; ++g) x[g] = agent_load(h + g * kCopyWords);
+                // (hipcc keeps atomic loads in program order and, left alone, sinks the additions between them: load,
+                // load, wait, add, ...  The empty asm needs all eight values at once, so the only wait sits behind the eighth.)
+                static_assert(kGlobalCopies == 8, "the asm below names eight registers");
+                asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+#pragma unroll
+                for (int g = 0; g < kGlobalCopies; ++g) v += x[g];
+            } else {
+                for (int g = 0; g < copies; ++g) v += agent_load(h + g * kCopyWords);
+            }
+        }
+        incl = v;  // inclusive scan within the wave
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        n = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];  // channel 0's total = the set's pixel count
+        if (n != 0u || set == 1) break;                             // (block-uniform)
+        __syncthreads();                                            // wave_tot is written again
     }
-    const uint32_t n = n0 != 0 ? n0 : n1;
     if (n == 0) {  // empty image (block-uniform)
         if (t == 0) out_rgba[0] = 0xff000000u;
         return;
     }
-    const uint32_t v = n0 != 0 ? v0 : v1;
     const uint32_t klo = (n - 1) / 2, khi = n / 2;
-    uint32_t incl = v;  // inclusive scan within the wave
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = __shfl_up(incl, off);
-        if (lane >= off) incl += up;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
     if (act) {
         for (int w = c * 4; w < wave; ++w) incl += wave_tot[w];
         const uint32_t excl = incl - v;
@@ -186,8 +184,7 @@ __device__ void median_select(const uint32_t *hist, int copies, uint32_t *out_rg
 // per-pixel index arithmetic).
 template <bool SELECT, bool STRIDED>
 __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBatch B) {
-    __shared__ uint32_t lh[2 * kSetWords * kCopies];
-    __shared__ uint32_t lcount[2];
+    __shared__ __attribute__((aligned(16))) uint32_t lh[2 * kSetWords * kCopies];
     __shared__ uint32_t wave_tot[kHistWaves];
     __shared__ uint32_t res[3][2];
     __shared__ uint32_t is_last;
@@ -196,11 +193,14 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBat
     // finished) -- is cleared by EVERY block of the grid, the ones without pixels of their own included, 16 bytes per
     // store: after a 16-image batch (0.8 MB) a small single-image call would otherwise zero all of it from one block,
     // in front of its first barrier.  Plain stores; the kernel boundary publishes them to the next call.
+    // (the block size as a constant: blockDim.x is a VECTOR load from the dispatch packet followed by s_waitcnt vmcnt(0),
+    // which would also wait for the image loads already in flight)
+    constexpr uint32_t kThreads = 64 * kHistWaves;
     auto clear_previous_half = [&]() {
         if (!B.zero_words) return;
-        const uint32_t n_thr = gridDim.x * gridDim.y * blockDim.x, n16 = B.zero_words >> 2;  // (slots are multiples of 16 bytes)
+        const uint32_t n_thr = gridDim.x * gridDim.y * kThreads, n16 = B.zero_words >> 2;  // (slots are multiples of 16 bytes)
         u32x4 *z = reinterpret_cast<u32x4 *>(B.zero_ptr);
-        for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < n16; i += n_thr) z[i] = u32x4{0u, 0u, 0u, 0u};
+        for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * kThreads + threadIdx.x; i < n16; i += n_thr) z[i] = u32x4{0u, 0u, 0u, 0u};
     };
     if (blockIdx.x >= I.blocks) {  // (block-uniform; such a block takes no ticket)
         clear_previous_half();
@@ -208,8 +208,7 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBat
     }
     const uint32_t *__restrict__ px = I.px;
     const size_t n_px = I.n_px;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t n_opaque = 0, n_clear = 0;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: trip bases and loop exits are wave-uniform)
     const size_t stride = (size_t)I.blocks * kHistWaves * kTripPx;
     size_t wbase = ((size_t)blockIdx.x * kHistWaves + wave) * kTripPx;
     const bool packed = !STRIDED || I.stride == I.w;  // block-uniform
@@ -222,8 +221,7 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBat
         for (int u = 0; u < kChunks; ++u)
             __builtin_memcpy(&ld[u], px + wbase + (size_t)u * 256 + (size_t)lane * 4, 16);
     }
-    for (int i = threadIdx.x; i < 2 * kSetWords * kCopies; i += blockDim.x) lh[i] = 0;
-    if (threadIdx.x < 2) lcount[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < 2 * kSetWords * kCopies / 4; i += kThreads) reinterpret_cast<u32x4 *>(lh)[i] = u32x4{0u, 0u, 0u, 0u};
     clear_previous_half();  // in the shadow of the loads above
     __syncthreads();
 
@@ -231,7 +229,7 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBat
         while (wbase + kTripPx <= n_px) {  // whole trips: wave-uniform, no guards
 #pragma unroll
             for (int u = 0; u < kChunks; ++u) {
-                hist_chunk<true>(ld[u][0], ld[u][1], ld[u][2], ld[u][3], true, true, true, true, lh, lane, n_opaque, n_clear);
+                hist_chunk<true>(ld[u][0], ld[u][1], ld[u][2], ld[u][3], true, true, true, true, lh, lane);
             }
             wbase += stride;
             if (wbase + kTripPx <= n_px) {
@@ -255,30 +253,34 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBat
                 if (!packed) at = (at / (uint32_t)I.w) * (size_t)I.stride + (at % (uint32_t)I.w);
                 p[j] = ok[j] ? px[at] : 0u;
             }
-            hist_chunk<false>(p[0], p[1], p[2], p[3], ok[0], ok[1], ok[2], ok[3], lh, lane, n_opaque, n_clear);
+            hist_chunk<false>(p[0], p[1], p[2], p[3], ok[0], ok[1], ok[2], ok[3], lh, lane);
         }
         if (packed) break;
     }
-    // wave-level count reductions (shuffle), one LDS add per wave and set
-    for (int off = 32; off > 0; off >>= 1) {
-        n_opaque += __shfl_down(n_opaque, off);
-        n_clear += __shfl_down(n_clear, off);
-    }
-    if (lane == 0) {
-        if (n_opaque) atomicAdd(&lcount[0], n_opaque);
-        if (n_clear) atomicAdd(&lcount[1], n_clear);
-    }
     __syncthreads();
 
+    // Flush: thread i adds bins 2i and 2i + 1 (of the 1536: [set][channel][256]) to the block's global copy with ONE
+    // 64-bit atomic -- the low word cannot carry into the high one, a bin holds at most the image's pixel count -- so a
+    // block sends at most 768 atomics instead of 1536 (a 4K noise image: 256 blocks x all bins).
     uint32_t *hist = I.hist;
     uint32_t *hist_copy = hist + (blockIdx.x & (I.copies - 1)) * kCopyWords;
-    for (int i = threadIdx.x; i < 2 * kSetWords; i += blockDim.x) {
-        uint32_t s = 0;
+    if (threadIdx.x < kSetWords) {
+        // the pair's 32 replica words as eight 16-byte reads, each thread starting at its own chunk: any eight
+        // neighbouring lanes then cover all 32 banks once
+        static_assert(kCopies == 16, "two bins x 16 replicas = eight 16-byte chunks");
+        const u32x4 *row = reinterpret_cast<const u32x4 *>(lh + 2 * threadIdx.x * kCopies);
+        uint32_t s0 = 0, s1 = 0;
 #pragma unroll
-        for (int k = 0; k < kCopies; ++k) s += lh[i * kCopies + ((k + threadIdx.x) & (kCopies - 1))];
-        if (s) atomicAdd(&hist_copy[i], s);
+        for (int k = 0; k < 8; ++k) {
+            const int c = (k + threadIdx.x) & 7;
+            const u32x4 q = row[c];
+            const uint32_t sum = q[0] + q[1] + q[2] + q[3];
+            s0 += c < 4 ? sum : 0u;
+            s1 += c < 4 ? 0u : sum;
+        }
+        if (s0 | s1)
+            atomicAdd(reinterpret_cast<unsigned long long *>(&hist_copy[2 * threadIdx.x]), (unsigned long long)s0 | ((unsigned long long)s1 << 32));
     }
-    if (threadIdx.x < 2 && lcount[threadIdx.x]) atomicAdd(&hist_copy[kCountOff + threadIdx.x], lcount[threadIdx.x]);
     if (!SELECT) return;  // two-launch form: the kernel boundary is the hand-off
 
     // Retirement ticket, without fences.  Everything a block publishes is an agent-scope ATOMIC (performed at the
@@ -358,10 +360,15 @@ hipError_t launch_median_batch(int k, const MedianView *views, uint32_t *const *
     for (int i = 0; i < k; ++i) strided |= B.img[i].stride != B.img[i].w;
     const dim3 grid(grid_x, (unsigned)k), block(64 * kHistWaves);
     // The two-launch form (kernel boundary + a one-block select launch instead of the ticket + the last block's
-    // read-back) is the measured alternative, MIC_MEDIAN_TWO_LAUNCHES=1: with one block per CU it is 0.6 us ahead at 4K
-    // (15.7 vs 16.3 us), level at 8K (31.8 vs 31.3), 0.6-1.1 us behind at the bundles' sizes and at 1080p
-    // (profiles/r03_median_experiments.txt) -- the one-launch form is the default everywhere.
-    if (two_launches == 1) {
+    // read-back): ahead once every CU has a block -- 256 blocks' tickets and flushes queue at the memory side -- 4K 10.0
+    // against 11.3 us, level at 8K (24.7 / 23.8), behind below that (1080p 9.4 / 7.8, bundle backgrounds 8.6 / 6.4;
+    // profiles/r04_median_experiments.txt).  two_launches < 0 picks by size; MIC_MEDIAN_TWO_LAUNCHES=1 / 0 force one form.
+    bool two = two_launches == 1;
+    if (two_launches < 0) {
+        two = true;
+        for (int i = 0; i < k; ++i) two &= B.img[i].n_px >= kTwoLaunchPx;
+    }
+    if (two) {
         if (strided) hipLaunchKernelGGL((median_kernel<false, true>), grid, block, 0, stream, B);
         else hipLaunchKernelGGL((median_kernel<false, false>), grid, block, 0, stream, B);
         hipLaunchKernelGGL(median_select_kernel, dim3((unsigned)k), block, 0, stream, B);

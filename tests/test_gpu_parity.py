@@ -202,8 +202,19 @@ def test_median_large_random_vs_oracle(gpu):
     # run back to back on one context: the kernel's last block must leave its scratch zeroed
     for (h, w, mode) in [(2160, 3840, "noise"), (1081, 1923, "flat"), (777, 1234, "sparse"),
                          (333, 1001, "clear_noise"), (4320, 7680, "clear_flat"), (1080, 1920, "flat_mixed_alpha"),
-                         (1, 3, "noise"), (2161, 3841, "blocks")]:
+                         (1, 3, "noise"), (2161, 3841, "blocks"), (2160, 3840, "one_colour"), (1500, 1999, "two_colours"),
+                         (2161, 3841, "one_colour_clear"), (600, 1024, "runs")]:
         a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+        if mode.startswith("one_colour"):  # every chunk of 256 pixels is one colour: the whole-chunk shortcut, both sets
+            a[:] = (220, 238, 245, 0 if mode.endswith("clear") else 255)
+        if mode == "two_colours":  # the boundary falls inside chunks (1999 px rows), one side transparent
+            a[:] = (10, 200, 30, 255)
+            a[:, 1000:] = (250, 3, 77, 0)
+            a[700:] = (9, 9, 9, 200)
+        if mode == "runs":  # runs of 256 equal pixels, chunk-aligned (1024 px rows), next to noise chunks
+            flat = rng.integers(0, 256, (h, w // 256, 1, 4), dtype=np.uint8)
+            a = np.where((np.arange(w // 256) % 3 != 0)[None, :, None, None], np.repeat(flat, 256, axis=2),
+                         a.reshape(h, w // 256, 256, 4)).reshape(h, w, 4)
         if mode in ("flat", "clear_flat", "flat_mixed_alpha"):  # mostly one colour: the wave-aggregation path
             a[:, :, :3] = (38, 73, 115)
             a[::7, ::5, :3] = rng.integers(0, 256, a[::7, ::5, :3].shape, dtype=np.uint8)
@@ -649,14 +660,16 @@ def test_median_batch_strided_views_and_long_batches(gpu):
         median_colors_device([dev[:, ::2]])  # pixels not adjacent
 
 
-def test_median_two_launch_form_agrees(gpu):
-    """The two-launch form of the median (histogram kernel + select kernel, MIC_MEDIAN_TWO_LAUNCHES=1 at mic_create;
-    kept as the measured alternative to the one-launch ticket) gives the same colours."""
+@pytest.mark.parametrize("two", ["1", "0"])
+def test_median_forced_launch_forms_agree(gpu, two):
+    """Both forms of the median -- one launch with a retirement ticket, or histogram kernel + select kernel -- at sizes on
+    either side of the size rule that picks between them by default (MIC_MEDIAN_TWO_LAUNCHES=1 / 0 at mic_create forces
+    one form for every size): the same colours as the oracle."""
     import ctypes
     import torch
     from image_transformation_amd import _native
     lib = _native.lib()
-    os.environ["MIC_MEDIAN_TWO_LAUNCHES"] = "1"
+    os.environ["MIC_MEDIAN_TWO_LAUNCHES"] = two
     try:
         h = ctypes.c_void_p()
         _native.check(lib.mic_create(gpu.device, ctypes.byref(h)))
@@ -664,8 +677,12 @@ def test_median_two_launch_form_agrees(gpu):
         del os.environ["MIC_MEDIAN_TWO_LAUNCHES"]
     try:
         rng = np.random.default_rng(32)
-        for shape in ((492, 492), (2160, 3840), (1, 1), (37, 1001)):
+        for shape in ((492, 492), (2160, 3840), (1, 1), (37, 1001), (3000, 4100)):
             a = rng.integers(0, 256, shape + (4,), dtype=np.uint8)
+            if shape[0] == 3000:  # flat with specks, mostly transparent
+                a[:, :, :3] = (1, 2, 254)
+                a[::11, ::13, :3] = 77
+                a[:, :, 3] = np.where(rng.random(shape) < 0.9, 0, a[:, :, 3])
             d = torch.from_numpy(a).to(gpu.torch_device)
             out = (ctypes.c_uint8 * 3)()
             for _ in range(2):
