@@ -132,6 +132,34 @@ while time.time() < t_end:
         print("MEDIAN BATCH MISMATCH", dict(seed=seed, shape=(mh, mw), n=len(views)))
         sys.exit(1)
     n_med += len(views)
+    # ---- one packed image through the single-image median: structured content (flat runs, few colours, mixed alpha
+    # classes) at sizes on both sides of the one-launch / two-launch rule
+    from image_transformation_amd.background_resizing import median_color_device
+    big = rng.random() < 0.15
+    bh, bw = (int(rng.integers(1500, 3000)), int(rng.integers(1500, 3200))) if big else (int(rng.integers(1, 700)), int(rng.integers(1, 1100)))
+    kind = int(rng.integers(0, 5))
+    if kind == 0:
+        b_np = rng.integers(0, 256, (bh, bw, 4), dtype=np.uint8)
+    elif kind == 1:  # one colour with specks
+        b_np = np.empty((bh, bw, 4), np.uint8); b_np[:] = rng.integers(0, 256, 4, dtype=np.uint8)
+        sp = rng.random((bh, bw)) < 0.002
+        b_np[sp] = rng.integers(0, 256, (int(sp.sum()), 4), dtype=np.uint8)
+    elif kind == 2:  # a palette of a few colours in runs of random length (chunks of 256 equal pixels and broken ones)
+        pal = rng.integers(0, 256, (int(rng.integers(1, 5)), 4), dtype=np.uint8)
+        pal[rng.random(len(pal)) < 0.4, 3] = 0
+        runs = np.repeat(rng.integers(0, len(pal), bh * bw // 64 + 2), rng.integers(1, 700, bh * bw // 64 + 2))[:bh * bw]
+        b_np = pal[runs].reshape(bh, bw, 4)
+    elif kind == 3:  # everything transparent: the all-pixels fallback
+        b_np = rng.integers(0, 256, (bh, bw, 4), dtype=np.uint8); b_np[:, :, 3] = 0
+    else:  # smooth gradient + a little noise (photo-like), alpha mostly opaque
+        gx = np.linspace(0, 255, bw)[None, :, None]; gy = np.linspace(0, 255, bh)[:, None, None]
+        b_np = np.clip(np.concatenate([gx + 0 * gy, gy + 0 * gx, (gx + gy) / 2, 255 + 0 * gx + 0 * gy], axis=2)
+                       + rng.normal(0, 3, (bh, bw, 4)), 0, 255).astype(np.uint8)
+    b_np = np.ascontiguousarray(b_np)
+    if median_color_device(torch.from_numpy(b_np).cuda()) != oracle.median_rgb(b_np):
+        print("MEDIAN MISMATCH", dict(seed=seed, shape=(bh, bw), kind=kind))
+        sys.exit(1)
+    n_med += 1
     # ---- a random resize
     sw, sh = int(rng.integers(1, 700)), int(rng.integers(1, 500))
     dw, dh = max(1, int(sw * rng.uniform(0.05, 3.0))), max(1, int(sh * rng.uniform(0.05, 3.0)))
