@@ -4,11 +4,11 @@ section 8f row 2).  Only its deterministic pieces are mirrored -- the start-pack
 (agentic/nodes/compositor.py:14-54: fill_solid + alpha-over with NO resizing, ValueError on a size
 mismatch).  The graph, the VLM nodes and the artifact writers are out of scope.
 
-Parity note: `agentic/` cannot be imported in the build container (it needs langgraph), so
-`placements_from_flex` is pinned only indirectly: tests check it against the main Flex placer
-(flex.py, which is pinned by fixtures) on trees where the two DSL dialects coincide
-(justify=start, align=start).  The pixel work is the identity-size subset of compositor.composite,
-which is pinned.
+Parity: `placements_from_flex` is pinned by tests/golden/agentic.json -- the reference's own
+function run by tests/golden/make_golden.py on 489 seeded trees (placements in dict order, or the
+exception type and message) -- and cross-checked against the main Flex placer (flex.py) on trees
+where the two DSL dialects coincide (justify=start, align=start).  The pixel work is the
+identity-size subset of compositor.composite, which is pinned.
 """
 from __future__ import annotations
 

@@ -336,6 +336,98 @@ FLEX_ERROR_NODES = [
     {"stick_to": {"edges": ["top"], "margin_px": -1}}, {"stick_to": {"edges": ["top"], "side": 1}},
 ]
 
+# ----------------------------------------------------------------------------- agentic placer (section 8f row 2)
+def _agentic_tree(rng, ids: List[int], depth: int, faults: bool) -> dict:
+    """A tree in the agentic dialect (direction / gap_px / padding_px / children only).  With `faults`
+    the node may carry what the reference must reject or tolerate: a bad or missing direction,
+    negative or string gap / padding, an empty container, string object ids."""
+    node: dict = {"direction": ["row", "column"][int(rng.integers(0, 2))]}
+    if rng.random() < 0.7:
+        node["gap_px"] = int(rng.integers(0, 25))
+    if rng.random() < 0.6:
+        node["padding_px"] = int(rng.integers(0, 17))
+    if faults:
+        r = rng.random()
+        if r < 0.10:
+            node["direction"] = ["diagonal", "ROW", "", None][int(rng.integers(0, 4))]
+        elif r < 0.16:
+            del node["direction"]
+        elif r < 0.24:
+            node["gap_px"] = -int(rng.integers(1, 9))
+        elif r < 0.32:
+            node["padding_px"] = -int(rng.integers(1, 9))
+        elif r < 0.40:
+            node["gap_px"] = str(int(rng.integers(0, 12)))      # int("7") is accepted
+        elif r < 0.46:
+            node["padding_px"] = ["3", "x", 2.9][int(rng.integers(0, 3))]
+        elif r < 0.50:
+            node["gap_px"] = [None, [1], 4.7][int(rng.integers(0, 3))]
+    children: List[dict] = []
+    rest = list(ids)
+    while rest:
+        if depth < 3 and len(rest) > 1 and rng.random() < 0.4:
+            k = int(rng.integers(1, len(rest) + 1))
+            children.append(_agentic_tree(rng, rest[:k], depth + 1, faults))
+            rest = rest[k:]
+        else:
+            oid: object = rest[0]
+            if faults and rng.random() < 0.08:
+                oid = str(oid)                                   # int("3") is accepted
+            children.append({"object_id": oid})
+            rest = rest[1:]
+    if faults and rng.random() < 0.07:
+        children.insert(int(rng.integers(0, len(children) + 1)),
+                        {"direction": "row", "padding_px": int(rng.integers(0, 5)), "children": []})
+    if faults and rng.random() < 0.04:
+        node["children"] = []
+    elif faults and rng.random() < 0.03:
+        pass                                                     # no "children" key at all
+    else:
+        node["children"] = children
+    return node
+
+
+def agentic_case(seed: int) -> dict:
+    """Seeded input of agentic/utils/layout.py:placements_from_flex: Flex JSON, canvas, object sizes."""
+    rng = np.random.default_rng(77_000 + seed)
+    n = int(rng.integers(1, 9))
+    sizes = {i + 1: [int(rng.integers(4, 300)), int(rng.integers(4, 220))] for i in range(n)}
+    ids = [int(i) for i in rng.permutation(np.arange(1, n + 1))]
+    faults = seed % 3 == 1
+    placed = list(ids)
+    kind = seed % 12
+    if kind == 5 and n > 1:
+        placed = placed[:-1]                                     # an object the layout forgets
+    if kind == 8:
+        placed = placed + [n + 1 + int(rng.integers(0, 3))]      # an id without a cutout (KeyError)
+    if kind == 11 and n > 1:
+        placed = placed + [placed[0]]                            # the same id twice: the later one wins
+    root = _agentic_tree(rng, placed, 1, faults)
+    flex: dict = {"root": root}
+    if seed % 40 == 17:
+        flex = {"layout": root}                                  # no "root"
+    if seed % 4 == 2:
+        W, H = int(rng.integers(20, 500)), int(rng.integers(20, 400))   # often too small
+    else:
+        W, H = int(rng.integers(600, 4000)), int(rng.integers(500, 3000))
+    return dict(name=f"agentic_{seed}", sizes=sizes, canvas=[W, H], flex=flex)
+
+
+N_AGENTIC = 480
+
+
+def agentic_bundle_case(k: int) -> dict:
+    """Fault-free trees over the squarespace bundle's four cutouts (sizes = SQUARESPACE_SIZES), so the
+    compositor node's pixels can be checked on placements the reference itself produced."""
+    rng = np.random.default_rng(78_000 + k)
+    ids = [int(i) for i in rng.permutation(np.arange(1, 5))]
+    root = _agentic_tree(rng, ids, 1, False)
+    return dict(name=f"agentic_sq_{k}", sizes={i: list(v) for i, v in SQUARESPACE_SIZES.items()},
+                canvas=[[492, 492], [970, 546], [1100, 800]][k % 3], flex={"root": root})
+
+
+N_AGENTIC_BUNDLE = 9
+
 # Nested-layout known answers on the squarespace bundle (SURVEY.md App. A.6)
 SQUARESPACE_SIZES = {1: [230, 62], 2: [357, 207], 3: [257, 137], 4: [131, 32]}
 

@@ -407,13 +407,51 @@ def gen_overlay():
     dump_json("overlay.json", {"meta": META, "cases": rows})
 
 
+def gen_agentic():
+    """agentic/utils/layout.py:106-121 `placements_from_flex` on the seeded trees of cases.agentic_case.
+
+    `agentic/state.py:9` imports the NAME `add_messages` from langgraph (absent from this image) for a
+    type annotation of the graph state; the placer never touches it.  The generator -- and nothing
+    else in this repo -- registers an empty-bodied placeholder for that one name so that the
+    reference's own state.py / layout.py can be imported unmodified; recorded in the fixture's meta."""
+    if "langgraph" not in sys.modules:
+        lg, lgg = types.ModuleType("langgraph"), types.ModuleType("langgraph.graph")
+        lgg.add_messages = lambda left, right: left  # annotation marker only; never called here
+        lg.graph = lgg
+        sys.modules["langgraph"], sys.modules["langgraph.graph"] = lg, lgg
+    from agentic.state import ObjectMeta as RefMeta  # noqa: E402  (reference)
+    from agentic.utils.layout import placements_from_flex as ref_place  # noqa: E402  (reference)
+
+    rows = []
+    todo = [cases.agentic_case(s) for s in range(cases.N_AGENTIC)] + \
+           [cases.agentic_bundle_case(k) for k in range(cases.N_AGENTIC_BUNDLE)]
+    for c in todo:
+        metas = {int(k): RefMeta(int(k), f"obj{k}", f"objects/o{k}.png", v[0], v[1]) for k, v in c["sizes"].items()}
+        row = {"name": c["name"], "sizes": {str(k): v for k, v in c["sizes"].items()}, "canvas": c["canvas"],
+               "flex": c["flex"], "placements": None, "error": None, "message": None}
+        try:
+            got = ref_place(copy.deepcopy(c["flex"]), tuple(c["canvas"]), metas)
+            # dict order is the order the compositor node blends in (agentic/nodes/compositor.py:36)
+            row["placements"] = [[p.object_id, p.name, p.x, p.y, p.width, p.height] for p in got.values()]
+            assert list(got.keys()) == [p.object_id for p in got.values()]
+        except Exception as e:  # noqa: BLE001
+            row["error"], row["message"] = type(e).__name__, str(e)
+        rows.append(row)
+    meta = dict(META, stub="sys.modules['langgraph.graph'].add_messages (placeholder; agentic/state.py:9 imports "
+                           "the name for an annotation, the placer never calls it)")
+    dump_json("agentic.json", {"meta": meta, "cases": rows})
+    n_err = sum(r["error"] is not None for r in rows)
+    print(f"agentic: {len(rows)} cases, {n_err} raise:",
+          sorted({(r['error'], (r['message'] or '')[:40]) for r in rows if r['error']}))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["bundles_copy", "canvas", "flex", "composite", "resize", "median", "bundles",
-                             "contact", "big", "c4", "gradient", "overlay"]
+                             "contact", "big", "c4", "gradient", "overlay", "agentic"]
     steps = {"bundles_copy": copy_bundles, "canvas": gen_canvas_sizes, "flex": gen_flex,
              "composite": gen_composite, "resize": gen_resize, "median": gen_median, "bundles": gen_bundles,
              "contact": gen_contact_sheets, "big": gen_big_hashes, "c4": gen_c4_all, "gradient": gen_gradient,
-             "overlay": gen_overlay}
+             "overlay": gen_overlay, "agentic": gen_agentic}
     for w in which:
         print("==", w, flush=True)
         steps[w]()

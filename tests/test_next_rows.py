@@ -1,15 +1,17 @@
 """SURVEY.md section 8f rows built after the hot path met its bar:
   * fill_gradient + edge-strip medians (background_resizing.py:36-98) -- pinned by fixtures captured
     from the reference (tests/golden/gradient.*);
-  * the agentic caller (agentic/utils/layout.py, agentic/nodes/compositor.py) -- langgraph is not
-    installed, so its placer is pinned only against the (fixture-pinned) main Flex placer on the
-    trees where the two dialects coincide; its pixel work is the identity-size subset of composite().
+  * the agentic caller (agentic/utils/layout.py, agentic/nodes/compositor.py) -- its placer is pinned
+    by tests/golden/agentic.json (the reference's own placements_from_flex on 489 seeded trees, incl.
+    every error it raises) and cross-checked against the main Flex placer where the two dialects
+    coincide; its pixel work is the identity-size subset of composite().
 """
 import json
 import os
 
 import numpy as np
 import pytest
+from PIL import Image
 
 import cases
 import oracle
@@ -105,6 +107,39 @@ def test_agentic_placer_agrees_with_main_placer_on_start_packed_trees():
         assert {k: [v.x, v.y, v.x + v.width, v.y + v.height] for k, v in got.items()} == want, trial
 
 
+def _agentic_fixture(golden_dir):
+    with open(os.path.join(golden_dir, "agentic.json"), encoding="utf-8") as f:
+        return json.load(f)["cases"]
+
+
+def test_agentic_placer_vs_reference_fixture(golden_dir):
+    """Every seeded tree of tests/golden/agentic.json (written by make_golden.py from the reference's
+    own agentic/utils/layout.py:106-121): same placements in the same dict order, or the same
+    exception type and message."""
+    import copy
+    from image_transformation_amd.agentic import placements_from_flex
+    rows = _agentic_fixture(golden_dir)
+    assert len(rows) >= 300
+    n_ok = n_err = 0
+    for r in rows:
+        # the generator is seeded: the stored input must be what cases.agentic_case makes today
+        k = int(r["name"].rsplit("_", 1)[1])
+        c = cases.agentic_bundle_case(k) if r["name"].startswith("agentic_sq_") else cases.agentic_case(k)
+        assert c["flex"] == r["flex"] and c["canvas"] == r["canvas"], r["name"]
+        metas = _metas({int(k): tuple(v) for k, v in r["sizes"].items()})
+        try:
+            got = placements_from_flex(copy.deepcopy(r["flex"]), tuple(r["canvas"]), metas)
+        except Exception as e:  # noqa: BLE001
+            assert (type(e).__name__, str(e)) == (r["error"], r["message"]), r["name"]
+            n_err += 1
+            continue
+        assert r["error"] is None, (r["name"], r["error"], r["message"])
+        assert [[p.object_id, p.name, p.x, p.y, p.width, p.height] for p in got.values()] == r["placements"], r["name"]
+        assert list(got.keys()) == [p[0] for p in r["placements"]], r["name"]
+        n_ok += 1
+    assert n_ok >= 150 and n_err >= 100
+
+
 def test_agentic_placer_errors():
     from image_transformation_amd.agentic import placements_from_flex
     metas = _metas({1: (10, 10), 2: (20, 5)})
@@ -149,6 +184,47 @@ def test_agentic_compositor_node_pixels(golden_dir):
     bad[2] = PlacementState(2, "o2", 0, 0, pls[2].width - 1, pls[2].height)
     with pytest.raises(ValueError, match="scaling objects is not permitted"):
         composite_placements(np.zeros((1, 1, 4)), objects, bad)
+
+
+@pytest.mark.gpu
+def test_agentic_compositor_node_on_reference_placements(golden_dir):
+    """The compositor node's pixels on placements the REFERENCE's placer produced
+    (tests/golden/agentic.json): the bundle-sized cases on the squarespace cutouts, and a sample of the
+    random cases on seeded synthetic cutouts of the recorded sizes; expected pixels from the oracle."""
+    from image_transformation_amd.agentic import PlacementState, composite_placements, compositor_node
+    from image_transformation_amd.compositor import load_object_images
+    rows = [r for r in _agentic_fixture(golden_dir) if r["error"] is None]
+    base = os.path.join(cases.BUNDLE_DIR, "squarespace")
+    objects = load_object_images(os.path.join(base, "results.json"))
+    arrays = {k: np.array(v) for k, v in objects.items()}
+    n = 0
+    for r in rows:
+        if not r["name"].startswith("agentic_sq_"):
+            continue
+        pls = {p[0]: PlacementState(*p) for p in r["placements"]}
+        W, H = r["canvas"]
+        out = np.array(compositor_node(os.path.join(base, "background.png"), (W, H), objects, pls))
+        want = oracle.composite(oracle.fill_solid((W, H), (220, 238, 245, 255)), arrays,
+                                [{"object_id": p[0], "box": [p[2], p[3], p[2] + p[4], p[3] + p[5]]} for p in r["placements"]])
+        assert np.array_equal(out, want), r["name"]
+        n += 1
+    assert n >= 5
+    rng = np.random.default_rng(9)
+    sample = [r for r in rows if not r["name"].startswith("agentic_sq_")][::9]
+    assert len(sample) >= 20
+    for r in sample:
+        cut = {}
+        for k, (w, h) in r["sizes"].items():
+            a = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+            a[..., 3] = np.where(rng.random((h, w)) < 0.3, 0, np.where(rng.random((h, w)) < 0.5, 255, a[..., 3]))
+            cut[int(k)] = a
+        pls = {p[0]: PlacementState(*p) for p in r["placements"]}
+        W, H = r["canvas"]
+        bg = oracle.fill_solid((W, H), (31, 200, 77, 255))
+        out = np.array(composite_placements(bg, {k: Image.fromarray(v, "RGBA") for k, v in cut.items()}, pls))
+        want = oracle.composite(bg, cut, [{"object_id": p[0], "box": [p[2], p[3], p[2] + p[4], p[3] + p[5]]}
+                                          for p in r["placements"]])
+        assert np.array_equal(out, want), r["name"]
 
 
 # ------------------------------------------------------------------------------------------ run_macro_only harness
