@@ -352,6 +352,41 @@ def timed_steps(D: Dist, ctx, plan, out_sets, steps, warmup):
     return elapsed, elapsed_min, kernel_ms, n_br
 
 
+def _golden_hashes(name: str):
+    """sha16 (first 16 hex digits of SHA-256 over the RGBA bytes) of canvases the REFERENCE rendered, captured by
+    tests/golden/make_golden.py in the build container: {fixture name: sha16}."""
+    with open(os.path.join(ROOT, "tests", "golden", name), encoding="utf-8") as f:
+        return {r["name"]: r["sha16"] for r in json.load(f)["cases"]}
+
+
+def verify_sets(D: Dist, out_sets, names, want):
+    """After a timed region, outside it: hash every canvas of every rotating output set the timed launches wrote whose
+    fixture name (names[i] for canvas i of a set; None = no fixture) is known, against the reference's own hash.
+    Every rank checks its own canvases -- on a multi-GPU run these are pixels of an atlas that crossed xGMI -- and
+    the verdicts are gathered.  -> {"verified": bool over all ranks, "canvases": distinct canvases checked over all
+    ranks, "checks": hashes compared (canvases x sets), "mismatches": [...]}"""
+    import hashlib
+
+    import torch
+
+    torch.cuda.synchronize()
+    bad, checks, seen = [], 0, set()
+    for s, outs in enumerate(out_sets):
+        for i, out in enumerate(outs):
+            if names[i] is None:
+                continue
+            got = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]
+            checks += 1
+            seen.add(names[i])
+            if got != want[names[i]]:
+                bad.append({"rank": D.rank, "set": s, "canvas": names[i], "got": got, "want": want[names[i]]})
+    rows = D.gather({"bad": bad, "checks": checks, "seen": sorted(seen)})
+    mism = [b for r in rows for b in r["bad"]]
+    return {"verified": not mism and sum(r["checks"] for r in rows) > 0,
+            "canvases": len({n for r in rows for n in r["seen"]}), "checks": sum(r["checks"] for r in rows),
+            "per_rank_checks": [r["checks"] for r in rows], "mismatches": mism[:8]}
+
+
 def c4_partition(n_var: int, world: int, sizes):
     """Who renders what in the strong-scaling leg: variant v -> rank v mod G (batch.shard_indices).  Pure: the CPU
     tests check the G = 8 split the driver's node will run (64 canvases, 8 per rank, ONE canvas class per rank: the
@@ -399,6 +434,11 @@ def c4_strong_leg(D: Dist, args, steps, warmup):
     n_sets = max(2, -(-(320 << 20) // max(set_bytes, 1)))  # outputs rotate over > 320 MB (here: 2 x 64/G canvases)
     out_sets = [plan.alloc_outputs() for _ in range(n_sets)]
     elapsed, elapsed_min, kernel_ms, n_br = timed_steps(D, ctx, plan, out_sets, steps, warmup)
+    # the pixels of the timed launches, after the clock has stopped: every canvas of every output set on every rank
+    # against the hash of the REFERENCE's render of that variant (tests/golden/c4_hashes.json; binary alpha, seed 4)
+    ver = None
+    if args.alpha == "binary":
+        ver = verify_sets(D, out_sets, [f"c4_variant_{v}" for v in mine], _golden_hashes("c4_hashes.json"))
     px_total = D.sum(float(st["canvas_pixels"]))
     canv_total = int(round(D.sum(float(len(mine)))))
     k_max, k_min = D.max_min(kernel_ms)
@@ -414,6 +454,10 @@ def c4_strong_leg(D: Dist, args, steps, warmup):
         "scaling": "strong", "value": round(px_total * steps / elapsed / 1e6, 1), "unit": "Mpixels/s",
         "canvases_total": canv_total, "canvases_per_rank": len(mine), "steps": steps, "warmup": warmup,
         "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "verified": ver["verified"] if ver else None, "verified_canvases": ver["canvases"] if ver else 0,
+        "verification": dict(ver, against="tests/golden/c4_hashes.json: the reference's own render of each variant "
+                                          "(compositor.py:6-22), every output set of every rank, after the timed region")
+        if ver else "no reference hashes for this alpha mode",
         "per_rank": {"timed_region_s_max": round(elapsed, 6), "timed_region_s_min": round(elapsed_min, 6),
                      "kernel_ms_max": round(k_max, 4), "kernel_ms_min": round(k_min, 4),
                      "roofline_frac_max": round(f_max, 4), "roofline_frac_min": round(f_min, 4),
@@ -577,7 +621,7 @@ def main():
                        "filter": "identity scale (Flex pipeline)"},
             "roofline": {"bound": "hbm", "achieved": round((leg["roofline_rank0"]["frac"] or 0) * HBM_PEAK_GBS, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": leg["roofline_rank0"]["frac"], "traffic": None,
-                         **leg["roofline_rank0"]},
+                         **leg["roofline_rank0"], "verified": leg["verified"], "verification": leg["verification"]},
             "per_rank": leg["per_rank"], "atlas": leg["atlas_broadcast"], "cpu_baseline": None, **ranks_info,
         }
         if dist_on:
@@ -590,6 +634,9 @@ def main():
                                                   sz, budget_s=args.cpu_budget)
         if rank == 0:
             print(json.dumps(result), flush=True)
+        if leg["verified"] is False:  # (every rank holds the gathered verdict: all of them leave non-zero)
+            raise SystemExit("bench.py: canvases of the timed launches differ from the reference's hashes: "
+                             + json.dumps(leg["verification"]["mismatches"]))
         return
 
     B = args.batch
@@ -635,6 +682,13 @@ def main():
     elapsed, elapsed_min, kernel_ms, n_br = timed_steps(D, ctx, plan, out_sets, args.steps, args.warmup)
     stats = plan.stats()
     kernel_ms_max, kernel_ms_min = D.max_min(kernel_ms)
+    # the pixels of the timed launches, checked after the clock has stopped (before any output set is released):
+    # layouts 0-2 of this workload were rendered by the REFERENCE in the build container (tests/golden/big_hashes.json);
+    # layout v lives on rank v mod G, so at G >= 3 three different GPUs each prove one canvas
+    head_ver = None
+    if args.alpha in ("binary", "soft") and B * world >= 3:
+        head_ver = verify_sets(D, out_sets, [f"c3_flex_{args.alpha}_{v}" if v < 3 else None for v in mine],
+                               _golden_hashes("big_hashes.json"))
 
     # HBM bytes per launch from the PMC counters, and the kernel's average duration by rocprofv3's kernel trace:
     # measured separately with rocprofv3 (bench.py cannot run under --pmc and time itself) and committed under
@@ -688,7 +742,11 @@ def main():
                      "dram": {"bytes": b_dram, "GBps": round(b_dram / (kernel_ms * 1e-3) / 1e9, 1) if kernel_ms > 0 else None,
                               "frac": frac(b_dram, kernel_ms),
                               "note": "bytes that must cross the HBM pins: canvases written once + the atlas read once"},
-                     "read_frac_of_peak": frac(b_read, kernel_ms)},
+                     "read_frac_of_peak": frac(b_read, kernel_ms),
+                     "verified": head_ver["verified"] if head_ver else None,
+                     "verification": dict(head_ver, against="tests/golden/big_hashes.json c3_flex_<alpha>_{0,1,2}: the "
+                                          "reference's own render of layouts 0-2, in every output set the timed launches wrote")
+                     if head_ver else "no reference hashes for this alpha mode / batch"},
         "atlas": {"bytes": atlas.nbytes, "first_ms": round(atlas_first_ms, 3), "warm_upload_or_broadcast_ms": round(atlas_warm_ms, 3),
                   "note": "first_ms includes HIP context creation and code-object load"},
         "host_layout_ms_per_image": {"python_mirror": round(layout_ms, 3),
@@ -730,6 +788,10 @@ def main():
 
     if rank == 0:
         print(json.dumps(result), flush=True)
+    failed = [name for name, v in (("headline", head_ver), ("c4_strong", result.get("c4_strong", {}).get("verification")))
+              if isinstance(v, dict) and not v["verified"]]
+    if failed:  # (every rank holds the gathered verdicts: all of them leave non-zero)
+        raise SystemExit(f"bench.py: canvases of the timed launches differ from the reference's hashes in {failed}")
 
 
 def _numpy_median_colour(img):

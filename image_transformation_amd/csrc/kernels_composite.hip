@@ -487,13 +487,19 @@ __global__ __launch_bounds__(64 * kPagesPerWorkgroup, (ALIGNED && SOLID) ? MIC_H
 static thread_local LayerPack g_pack;
 
 hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_jobs, const int class_end[3],
-                            int pitch, const Job *single, const Layer *single_layers_host, hipStream_t stream) {
+                            int pitch, const Job *single, const Layer *single_layers_host, hipStream_t stream,
+                            uint64_t *launched_workgroups) {
+    // every launch below covers `pitch` pages per job with workgroups of kPagesPerWorkgroup pages; what is reported
+    // is computed from the very grid that is launched (mic_stats.composite_blocks, tests/test_gpu_parity.py)
+    if (launched_workgroups) *launched_workgroups = 0;
     if (n_jobs <= 0 || pitch <= 0) return hipSuccess;
+    const unsigned wgs = (unsigned)pitch / kPagesPerWorkgroup;
+    if (launched_workgroups) *launched_workgroups = (uint64_t)wgs * (uint64_t)n_jobs;
     // grid.x (= pitch) is a multiple of 8 so that (linear workgroup id) mod 8 == (page index) mod 8
     // for every job of the launch: the XCD <-> page residue pairing survives the 2-D grid.
     const int b[5] = {0, class_end[0], class_end[1], class_end[2], n_jobs};
     if (single && n_jobs == 1) {
-        const dim3 grid((unsigned)pitch, 1u);
+        const dim3 grid(wgs, 1u);
         const int cls = b[1] > b[0] ? 0 : b[2] > b[1] ? 1 : b[3] > b[2] ? 2 : 3;
         if (single_layers_host && single->layer_count <= kPackLayers) {
             Job one = *single;
@@ -517,16 +523,16 @@ hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_
     }
     const Job none{};
     if (b[1] > b[0])
-        hipLaunchKernelGGL((composite_kernel<true, true, kFromTables>), dim3((unsigned)pitch / kPagesPerWorkgroup, (unsigned)(b[1] - b[0])), dim3(64 * kPagesPerWorkgroup),
+        hipLaunchKernelGGL((composite_kernel<true, true, kFromTables>), dim3(wgs, (unsigned)(b[1] - b[0])), dim3(64 * kPagesPerWorkgroup),
                            0, stream, jobs_dev + b[0], layers_dev, none, g_pack);
     if (b[2] > b[1])
-        hipLaunchKernelGGL((composite_kernel<false, true, kFromTables>), dim3((unsigned)pitch / kPagesPerWorkgroup, (unsigned)(b[2] - b[1])), dim3(64 * kPagesPerWorkgroup),
+        hipLaunchKernelGGL((composite_kernel<false, true, kFromTables>), dim3(wgs, (unsigned)(b[2] - b[1])), dim3(64 * kPagesPerWorkgroup),
                            0, stream, jobs_dev + b[1], layers_dev, none, g_pack);
     if (b[3] > b[2])
-        hipLaunchKernelGGL((composite_kernel<true, false, kFromTables>), dim3((unsigned)pitch / kPagesPerWorkgroup, (unsigned)(b[3] - b[2])), dim3(64 * kPagesPerWorkgroup),
+        hipLaunchKernelGGL((composite_kernel<true, false, kFromTables>), dim3(wgs, (unsigned)(b[3] - b[2])), dim3(64 * kPagesPerWorkgroup),
                            0, stream, jobs_dev + b[2], layers_dev, none, g_pack);
     if (b[4] > b[3])
-        hipLaunchKernelGGL((composite_kernel<false, false, kFromTables>), dim3((unsigned)pitch / kPagesPerWorkgroup, (unsigned)(b[4] - b[3])), dim3(64 * kPagesPerWorkgroup),
+        hipLaunchKernelGGL((composite_kernel<false, false, kFromTables>), dim3(wgs, (unsigned)(b[4] - b[3])), dim3(64 * kPagesPerWorkgroup),
                            0, stream, jobs_dev + b[3], layers_dev, none, g_pack);
     return hipGetLastError();
 }

@@ -1574,13 +1574,12 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     // this runtime, and the composite starves inside the resample kernel's register / LDS budget.
     // profiles/r04_pipeline_streams.txt, r04_fused_launches.txt, r04_overlap_experiments.patch.)
     HIP_TRY(launch_composite(jobs_dev, layers_dev, n_jobs, class_end, pitch, one ? &P->ordered[0] : nullptr,
-                             pack_layers ? P->layers.data() : nullptr, stream));
+                             pack_layers ? P->layers.data() : nullptr, stream, &P->stats.composite_blocks));
     if (prof) {
         HIP_TRY(hipEventRecord(pe[2], stream));
         ++ctx->prof_calls;
     }
     if (P->persistent) P->resampled_valid = true;
-    P->stats.composite_blocks = (uint64_t)(pitch / kPagesPerWorkgroup) * n_jobs;
     ctx->stats = P->stats;
     return MIC_OK;
 }

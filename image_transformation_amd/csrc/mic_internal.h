@@ -142,13 +142,15 @@ constexpr int kRsTilesPerEntry = 32;
 // ---- launchers (defined next to their kernels) -----------------------------------------------
 // The job table is sorted by kernel class; class_end[c] = one past the last job of class c for
 // c = 0 (aligned + solid opaque background), 1 (unaligned + solid), 2 (aligned + other background);
-// the rest is class 3.  pitch = max pages per job rounded up to 8.
+// the rest is class 3.  pitch = max PAGES per job rounded up to 8 * kPagesPerWorkgroup; every launch (batch or
+// single job) dispatches pitch / kPagesPerWorkgroup workgroups per job, and *launched_workgroups says how many.
 // single != nullptr (n_jobs == 1): the job rides in the kernel arguments; single_layers_host != nullptr and at most
 // kPackLayers layers: so do its layer records (host array, indexed by the job's layer_begin) -- nothing is read from
 // jobs_dev / layers_dev then.
 constexpr int kPackLayers = 64;
 hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_jobs, const int class_end[3],
-                            int pitch, const Job *single, const Layer *single_layers_host, hipStream_t stream);
+                            int pitch, const Job *single, const Layer *single_layers_host, hipStream_t stream,
+                            uint64_t *launched_workgroups);
 hipError_t launch_resample_h(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_rows,
                              hipStream_t stream);
 hipError_t launch_resample_v(const RsJob *jobs_dev, int n_jobs, int max_out_w, int max_out_h,

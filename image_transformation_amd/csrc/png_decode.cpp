@@ -596,6 +596,13 @@ int png_decode_rows(const uint8_t *data, size_t n, uint8_t *const *rows, int32_t
     const size_t row_bytes = ((size_t)w * (size_t)channels * (size_t)P.depth + 7) / 8;
     const int bpp = std::max(1, channels * P.depth / 8);
     const size_t raw_n = (size_t)h * (row_bytes + 1);
+    // DEFLATE expands at most 1032 : 1 (a 258-byte match per 2 bits): a stream too short to hold the scanlines the
+    // header promises is refused BEFORE h * (row_bytes + 1) bytes are allocated for it (a 65535 x 65535 IHDR in front
+    // of a few bytes of IDAT must not cost 17 GB)
+    if (P.idat_n < 6 || raw_n / 1032 > P.idat_n) {
+        if (err) *err = "png: the IDAT stream cannot hold the image the header declares";
+        return kPngMalformed;
+    }
     std::unique_ptr<uint8_t[]> raw(new (std::nothrow) uint8_t[raw_n + 16]);
     if (!raw) {
         if (err) *err = "png: out of memory";

@@ -158,6 +158,11 @@ def decode_many(blobs, threads: int = 0):
     for i, b in enumerate(blobs):
         if lib.mic_png_info(b, len(b), ctypes.byref(w), ctypes.byref(h)) != 0:
             continue
+        # Pillow's decompression-bomb guard belongs to the reference's Image.open(path) (compositor.py:34): above
+        # MAX_IMAGE_PIXELS it warns, above twice that it raises DecompressionBombError.  Such a file is DECLINED here,
+        # before anything is allocated for it, so Pillow opens it and warns / raises exactly as it always did.
+        if Image.MAX_IMAGE_PIXELS is not None and w.value * h.value > Image.MAX_IMAGE_PIXELS:
+            continue
         im, table = _new_rgba(w.value, h.value)
         if table is None:  # Pillow's memory cannot be located: decode into an array, then wrap it
             arr = np.empty((h.value, w.value, 4), np.uint8)

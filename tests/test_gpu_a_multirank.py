@@ -76,6 +76,13 @@ def test_bench_protocol_with_two_ranks():
     assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["cores"] == 1 and rec["cpu_baseline"]["value"] > 0
     # the strong-scaling extra does not inherit --steps: >= 200 timed steps behind >= 20 warm-up ones
     assert rec["c4_strong"]["steps"] >= 200 and rec["c4_strong"]["warmup"] >= 20 and rec["c4_strong"]["canvases_total"] == 64
+    # the line proves its own pixels: layouts 0-2 (rank 0 holds 0 and 2, rank 1 holds 1) against the reference's hashes in
+    # every output set, and all 64 C4 variants, each on the rank that rendered it
+    hv = rec["roofline"]["verification"]
+    assert rec["roofline"]["verified"] is True and hv["canvases"] == 3 and all(n > 0 for n in hv["per_rank_checks"]), hv
+    cv = rec["c4_strong"]["verification"]
+    assert rec["c4_strong"]["verified"] is True and rec["c4_strong"]["verified_canvases"] == 64, cv
+    assert len(cv["per_rank_checks"]) == 2 and all(n >= 32 for n in cv["per_rank_checks"]) and not cv["mismatches"], cv
 
 
 def _bench(args, env=None, timeout=600):
@@ -107,6 +114,8 @@ def test_bench_self_launch_c4_two_ranks():
     assert pr["canvas_sizes"] == [[[2160, 3840], [3840, 2160]], [[2880, 2880], [4399, 1885]]]
     assert rec["atlas"]["bytes"] > 15_000_000 and rec["atlas"]["warm_ms_max"] > 0
     assert rec["value"] > 0 and abs(rec["ms_per_step"] - pr["timed_region_s_max"] / 6 * 1e3) < 1e-3
+    assert rec["roofline"]["verified"] is True and rec["roofline"]["verification"]["canvases"] == 64
+    assert rec["roofline"]["verification"]["per_rank_checks"] == [64, 64]  # 32 canvases x 2 output sets per rank
 
 
 def test_bench_self_launch_c4_four_ranks():
@@ -121,6 +130,9 @@ def test_bench_self_launch_c4_four_ranks():
     assert rec["config"]["canvases_per_step_total"] == 64 and rec["config"]["canvases_per_step_per_gpu"] == 16
     assert rec["per_rank"]["canvas_sizes"] == [[[2160, 3840]], [[2880, 2880]], [[3840, 2160]], [[4399, 1885]]]
     assert rec["cpu_baseline"]["value"] > 0 and rec["value"] > 0
+    ver = rec["roofline"]["verification"]
+    assert rec["roofline"]["verified"] is True and ver["canvases"] == 64 and len(ver["per_rank_checks"]) == 4, ver
+    assert all(n >= 16 for n in ver["per_rank_checks"]) and not ver["mismatches"], ver
 
 
 def test_bench_c4_single_gpu_agrees_with_the_mixed_batch_leg():
@@ -132,6 +144,9 @@ def test_bench_c4_single_gpu_agrees_with_the_mixed_batch_leg():
     assert c4["ranks"] == 1 and c4["scaling"] == "strong" and c4["config"]["canvases_per_step_total"] == 64
     full = _bench(["--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
     assert full["scaling"] == "weak" and full["c4_strong"]["canvases_total"] == 64
+    assert c4["roofline"]["verified"] is True and c4["roofline"]["verification"]["canvases"] == 64
+    assert full["roofline"]["verified"] is True and full["roofline"]["verification"]["canvases"] == 3
+    assert full["c4_strong"]["verified"] is True and full["c4_strong"]["verified_canvases"] == 64
     assert abs(full["c4_strong"]["value"] / c4["value"] - 1) < 0.05, (full["c4_strong"]["value"], c4["value"])
     mixed = full["mixed_c4_batch"]["Mpixels_per_s"]
     assert abs(c4["value"] / mixed - 1) < 0.05, (c4["value"], mixed)

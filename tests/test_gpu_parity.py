@@ -888,3 +888,46 @@ def test_solid_canvas_with_a_device_colour_word(gpu):
     atl = (ctypes.c_void_p * 1)(atlas.handle)
     assert lib.mic_composite_batch(gpu.handle, 1, atl, 1, ctypes.byref(job), 0, ctypes.c_void_p(gpu.stream_ptr())) < 0
     assert b"both a background image and a device colour word" in lib.mic_last_error()
+
+
+def test_single_canvas_launch_dispatches_no_surplus_workgroups(gpu):
+    """One canvas per call is the reference's own call shape (compositor.py:6-22).  Round 4 shipped a single-job launch
+    that dispatched one four-wave workgroup per PAGE (three quarters of its waves returned at once; results were
+    right, so no parity test saw it).  mic_stats.composite_blocks is computed from the grid that is launched: for
+    every instantiation (aligned x solid) and both single-job modes (layer records in the kernel arguments: <= 64
+    layers; job only: more) it must cover the canvas' 4 KiB pages with less than one round of 8 workgroups to spare."""
+    import torch
+    from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
+    syn = cases.synthetic
+    objs = syn.make_cutouts(6, (30, 90), (20, 70), seed=77, alpha_mode="soft")
+    atlas = Atlas(objs)
+    rng = np.random.default_rng(5)
+    kp = 4  # kPagesPerWorkgroup (mic_internal.h)
+    seen = set()
+    for (W, H) in [(492, 492), (1920, 1080), (3840, 2160), (7680, 4320), (4399, 1885), (1023, 64)]:
+        for solid in (True, False):
+            for n_layers in (5, 70):
+                pl = []
+                for k in range(n_layers):
+                    oid = int(rng.integers(1, 7))
+                    sh, sw = objs[oid].shape[:2]
+                    x1, y1 = int(rng.integers(-20, W - 10)), int(rng.integers(-20, H - 10))
+                    pl.append({"object_id": oid, "box": [x1, y1, x1 + sw, y1 + sh]})
+                rows = coerce_placements(atlas, pl)
+                if solid:
+                    bg_np = oracle.fill_solid((W, H), syn.SOLID_BG)
+                    canvas = SolidCanvas((W, H), syn.SOLID_BG)
+                else:
+                    bg_np = np.empty((H, W, 4), np.uint8)
+                    bg_np[...] = rng.integers(0, 256, (1, W, 4), dtype=np.uint8)
+                    bg_np[..., 3] = 255
+                    canvas = torch.from_numpy(bg_np).to(gpu.torch_device)
+                out = composite_device(atlas, [canvas], [rows])[0]
+                st = gpu.stats()
+                out_np = out.cpu().numpy()
+                n_pages = (W * H + (out.data_ptr() % 4096) // 4 + 1023) // 1024
+                covered = st["composite_blocks"] * kp
+                assert n_pages <= covered < n_pages + 8 * kp, ((W, H), solid, n_layers, st["composite_blocks"], n_pages)
+                assert np.array_equal(out_np, oracle.composite(bg_np, objs, pl)), ((W, H), solid, n_layers)
+                seen.add((W % 4 == 0, solid, n_layers <= 64))
+    assert len(seen) == 8  # four instantiations x {kAllInArgs, kJobInArgs}

@@ -221,7 +221,7 @@ def test_agentic_compositor_node_on_reference_placements(golden_dir):
         pls = {p[0]: PlacementState(*p) for p in r["placements"]}
         W, H = r["canvas"]
         bg = oracle.fill_solid((W, H), (31, 200, 77, 255))
-        out = np.array(composite_placements(bg, {k: Image.fromarray(v, "RGBA") for k, v in cut.items()}, pls))
+        out = np.array(composite_placements(Image.fromarray(bg, "RGBA"), {k: Image.fromarray(v, "RGBA") for k, v in cut.items()}, pls))
         want = oracle.composite(bg, cut, [{"object_id": p[0], "box": [p[2], p[3], p[2] + p[4], p[3] + p[5]]}
                                           for p in r["placements"]])
         assert np.array_equal(out, want), r["name"]

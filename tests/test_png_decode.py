@@ -153,6 +153,45 @@ def test_declines_what_it_does_not_take(tmp_path):
     assert after[1] > before[1]
 
 
+def test_decompression_bombs_are_left_to_pillow(tmp_path, monkeypatch):
+    """a 65535 x 65535 IHDR in front of a few bytes of IDAT.  The Python level declines anything above
+    Pillow's MAX_IMAGE_PIXELS without allocating (so open_rgba raises Pillow's DecompressionBombError, as the
+    reference's Image.open does); with the guard lifted the native reader still refuses the file before it allocates
+    17 GB (an IDAT stream of n bytes cannot inflate to more than 1032 n); a file just above the limit decodes through
+    Pillow with Pillow's warning."""
+    import ctypes
+    import resource
+    from image_transformation_amd import _native, png as mic_png
+    from image_transformation_amd.compositor import open_rgba
+    small = Image.fromarray(np.full((3, 5, 4), 200, np.uint8), "RGBA")
+    ch = _chunks(_png_bytes(small))
+    bomb = _assemble([(b"IHDR", struct.pack(">IIBBBBB", 65535, 65535, 8, 6, 0, 0, 0))] + ch[1:])
+    w, h = ctypes.c_int32(), ctypes.c_int32()
+    assert _native.lib().mic_png_info(bomb, len(bomb), ctypes.byref(w), ctypes.byref(h)) == 0 and (w.value, h.value) == (65535, 65535)
+    rss0 = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss
+    assert mic_png.decode(bomb) is None
+    p = tmp_path / "bomb.png"
+    p.write_bytes(bomb)
+    with pytest.raises(Image.DecompressionBombError):
+        open_rgba(str(p))
+    # the native guard on its own: hand mic_png_decode_rows a row table of the right length (never written: the call
+    # must fail before it touches a row) and see that it neither succeeds nor allocates
+    rows = (ctypes.c_void_p * 65535)()
+    assert _native.lib().mic_png_decode_rows(bomb, len(bomb), rows, 65535, 65535) != 0
+    assert resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - rss0 < 200_000  # KiB: nowhere near 17 GB
+    # between the limit and twice the limit Pillow only warns: the file is declined and decoded by Pillow, warning included
+    monkeypatch.setattr(Image, "MAX_IMAGE_PIXELS", 1000)
+    mid = Image.fromarray(np.random.default_rng(3).integers(0, 256, (30, 50, 4), dtype=np.uint8), "RGBA")
+    blob = _png_bytes(mid)
+    assert mic_png.decode(blob) is None
+    q = tmp_path / "mid.png"
+    q.write_bytes(blob)
+    with pytest.warns(Image.DecompressionBombWarning):
+        assert open_rgba(str(q)).tobytes() == mid.tobytes()
+    monkeypatch.setattr(Image, "MAX_IMAGE_PIXELS", None)  # the guard switched off, as Pillow allows
+    assert mic_png.decode(blob).tobytes() == mid.tobytes()
+
+
 def test_load_object_images_goes_through_the_reader(golden_dir, monkeypatch):
     """load_object_images (compositor.py:25-35) decodes a bundle's cutouts with libmic's reader, all files of the first
     load together; the images equal Pillow's; later loads read the decode cache."""
