@@ -313,6 +313,11 @@ class Atlas(Mapping):
     (the reference re-decodes the PNGs each iteration, macro_placement_test.py:1493,1679).
     Behaves as a read-only mapping id -> entry with `.size`, which is all the layout code
     needs (macro_placement_test.py:645,708 only read img.size).
+
+    The blob is IMMUTABLE while the Atlas exists (also one made by from_blob over a caller's tensor):
+    libmic keeps data derived from it -- planar copies of cutouts that get resampled, resampled layers
+    in plans and in the context's layer cache -- and cannot see the bytes being rewritten in place.  To
+    show other pixels, build a new Atlas (and new CompositeBatch plans) over them.
     """
 
     def __init__(self, objects: Mapping[int, Any], device: Optional[int] = None, ctx: Optional[_native.Context] = None):
@@ -361,7 +366,8 @@ class Atlas(Mapping):
 
     @classmethod
     def from_blob(cls, blob, device: Optional[int] = None) -> "Atlas":
-        """Wrap a device blob (e.g. the result of a torch.distributed broadcast)."""
+        """Wrap a device blob (e.g. the result of a torch.distributed broadcast).  The tensor must not be written
+        again while this Atlas (or a plan built on it) is in use: see the class docstring."""
         self = cls.__new__(cls)
         self.ctx = _native.context(device if device is not None else blob.device.index)
         self._init_from_blob(blob)

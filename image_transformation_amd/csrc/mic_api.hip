@@ -210,6 +210,12 @@ struct mic_ctx {
     // Work units a call's resampled layers must add up to before they take the marching kernel (two workgroups
     // per CU); MIC_RS_MARCH_MIN_UNITS at mic_create (tests set 0 to run every qualifying layer through it).
     int64_t march_min_units = 512;
+    // The lane kernel (kernels_resample_lane.hip, round 5) takes the layers that qualify for it once the call's
+    // resampling adds up to at least this many wave slots of work; MIC_RS_LANE=0 leaves them to the marching / tile
+    // kernels (A/B runs, the marching kernel's own tests), MIC_RS_LANE_MIN_SLOTS moves the threshold (0: every
+    // qualifying layer), MIC_RS_LANE_SLOTS caps the slots of a launch (default 4096 = 256 CUs x 4 SIMDs x 4 waves).
+    bool lane_on = true;
+    int lane_min_slots = 256, lane_max_slots = 4096;
     uint32_t *median_scratch = nullptr;  // device: two sets of histogram slots (a double buffer) + kMedianMaxBatch result words
     MedianState median_state;            // which half the next call works in, what the previous one left to clear
     bool layer_args = true;              // MIC_LAYER_ARGS=0: single-canvas launches read their layer records from the device table
@@ -270,6 +276,12 @@ struct mic_atlas {
     mutable std::vector<uint64_t> planar_off;   // per entry, bytes from `planar`
     mutable std::vector<int32_t> planar_pitch;
     mutable std::vector<uint8_t> planar_built;  // per entry
+    // The same for the lane kernel: TILED planar copies (planes of 16 x 16 tiles, band by band; tiles per band =
+    // ceil(w / 16) + 3, so that the 4-tile window that starts at any tile of a row stays inside its band).
+    mutable std::shared_ptr<FragBuffer> tiled;
+    mutable std::vector<uint64_t> tiled_off;
+    mutable std::vector<int32_t> tiled_ct;      // tiles per band
+    mutable std::vector<uint8_t> tiled_built;
 };
 
 // Lock the context for the rest of the calling function and make its device current.
@@ -300,6 +312,9 @@ extern "C" int mic_create(int device, mic_ctx **out) {
     if (const char *mb = getenv("MIC_FRAG_CACHE_MB"))
         if (atoi(mb) > 0) ctx->frag_cache_cap = (size_t)atoi(mb) << 20;
     if (const char *mu = getenv("MIC_RS_MARCH_MIN_UNITS")) ctx->march_min_units = std::max<long long>(0, atoll(mu));
+    if (const char *ln = getenv("MIC_RS_LANE")) ctx->lane_on = atoi(ln) != 0;
+    if (const char *ln = getenv("MIC_RS_LANE_MIN_SLOTS")) ctx->lane_min_slots = std::max(0, atoi(ln));
+    if (const char *ln = getenv("MIC_RS_LANE_SLOTS")) ctx->lane_max_slots = std::min(65536, std::max(32, atoi(ln) / 32 * 32));
     for (auto &s : ctx->slots) {
         e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
         if (e != hipSuccess) {
@@ -437,14 +452,14 @@ static int get_coefs(mic_ctx *ctx, int in, int out, int filter, bool transposed,
 // A table met for the first time is carved from the context's current slab and uploaded by one asynchronous copy on
 // `stream` (the stream of the call that needs it: its kernels follow on the same stream; a later call on another stream
 // is ordered behind it by adopt_stream()).
-static int get_frags(mic_ctx *ctx, int in, int out, int filter, hipStream_t stream, FragEntry *res) {
-    const CoefKey key{in, out, in == out ? -1 : filter, 0};
+static int get_frags(mic_ctx *ctx, int in, int out, int filter, hipStream_t stream, FragEntry *res, int form = kFragsTile) {
+    const CoefKey key{in, out, in == out ? -1 : filter, form};  // (.transposed carries the fragment form: resample_coeffs.h)
     auto it = ctx->frags.find(key);
     if (it != ctx->frags.end()) {
         *res = it->second;
         return MIC_OK;
     }
-    const AxisFrags f = build_axis_frags(in == out ? identity_axis_table(in) : build_axis_table(in, out, filter));
+    const AxisFrags f = build_axis_frags(in == out ? identity_axis_table(in) : build_axis_table(in, out, filter), form);
     FragEntry e;
     e.tiles = f.tiles;
     e.max_chunks = f.max_chunks;
@@ -708,6 +723,63 @@ static int atlas_planar_build(const mic_atlas *A, const std::vector<int> &need, 
     return MIC_OK;
 }
 
+// The TILED planar copies the lane kernel reads (kernels_resample_lane.hip: planarize_tiled_kernel): same life cycle as
+// the row-major copies above -- addresses fixed when a plan is built, pixels converted by the first run that needs them.
+static int atlas_tiled_alloc(const mic_atlas *A) {
+    mic_ctx *ctx = A->ctx;
+    const size_t n = A->entries.size();
+    if (!A->tiled) {
+        std::vector<uint64_t> off(n);
+        std::vector<int32_t> cts(n);
+        size_t total = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const BlobEntry &e = A->entries[i];
+            const int ct = (e.w + 15) / 16 + 3, bands = (e.h + 15) / 16;
+            off[i] = total;
+            cts[i] = ct;
+            total = align_up(total + (size_t)4 * bands * ct * 256, 256);
+        }
+        auto buf = std::make_shared<FragBuffer>();
+        buf->device = ctx->device;
+        buf->bytes = total + 4096;  // (slack: nothing reads past a plane, the margin is for good measure)
+        HIP_TRY(hipMalloc(&buf->dev, buf->bytes));
+        A->tiled_off = std::move(off);
+        A->tiled_ct = std::move(cts);
+        A->tiled_built.assign(n, 0);
+        A->tiled = std::move(buf);
+    }
+    return MIC_OK;
+}
+
+static int atlas_tiled_build(const mic_atlas *A, const std::vector<int> &need, hipStream_t stream) {
+    mic_ctx *ctx = A->ctx;
+    if (int rc = atlas_tiled_alloc(A)) return rc;
+    std::vector<PlanarJob> jobs;
+    std::vector<int> building;
+    int64_t max_items = 0;
+    for (int i : need) {
+        if (A->tiled_built[(size_t)i] || std::find(building.begin(), building.end(), i) != building.end()) continue;
+        building.push_back(i);
+        const BlobEntry &e = A->entries[(size_t)i];
+        PlanarJob j{};
+        j.src = reinterpret_cast<uint64_t>(A->blob) + e.offset;
+        j.dst = reinterpret_cast<uint64_t>(A->tiled->dev) + A->tiled_off[(size_t)i];
+        j.w = e.w; j.h = e.h; j.pitch = 16 * A->tiled_ct[(size_t)i];
+        jobs.push_back(j);
+        max_items = std::max<int64_t>(max_items, (int64_t)(j.pitch / 4) * ((e.h + 15) / 16 * 16));
+    }
+    if (jobs.empty()) return MIC_OK;
+    Slot *slot = nullptr;
+    if (int rc = acquire_slot(ctx, sizeof(PlanarJob) * jobs.size(), &slot)) return rc;
+    memcpy(slot->host, jobs.data(), sizeof(PlanarJob) * jobs.size());
+    HIP_TRY(hipMemcpyAsync(slot->dev, slot->host, sizeof(PlanarJob) * jobs.size(), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(slot->ev, stream));
+    slot->pending = true;
+    HIP_TRY(launch_planarize_tiled(static_cast<const PlanarJob *>(slot->dev), (int)jobs.size(), max_items, stream));
+    for (int i : building) A->tiled_built[(size_t)i] = 1;
+    return MIC_OK;
+}
+
 // ------------------------------------------------------------------------------------ resample planning
 namespace {
 
@@ -730,6 +802,11 @@ struct ResizePlan {
     int planar_pitch = 0;
     int atlas = -1, entry = -1;  // where the source is a cutout of an atlas
     bool cached = false;  // the pixels are in the context's resident layer cache already (dst_ptr): no pass is emitted
+    // lane kernel (one wave per piece, tiled planar source)
+    bool lane_ok = false;  // the layer qualifies (a cutout of an atlas; both axes have lane tables: max_chunks == 1)
+    bool lane = false;     // ... and the call routes it there
+    uint64_t tiled_src = 0;
+    int tiled_ct = 0;
 };
 
 struct PassTables {
@@ -742,6 +819,10 @@ struct PassTables {
     size_t lds_march = 0;
     std::vector<RsJob> h, v;
     int max_h_out_w = 0, max_h_rows = 0, max_v_out_w = 0, max_v_out_h = 0;
+    // lane kernel: pieces, and per wave slot the [begin, end) of its pieces (slots: a multiple of 32)
+    std::vector<RsLaneUnit> lane;
+    std::vector<uint32_t> lane_ranges;
+    int lane_slots = 0, lane_layers = 0;
 };
 
 // Over all groups of `per` consecutive 16-sample tiles along one axis: the largest window extent a
@@ -828,6 +909,124 @@ int choose_march(mic_ctx *ctx, ResizePlan *p, int filter, hipStream_t stream) {
     return MIC_OK;
 }
 
+// Does the layer qualify for the lane kernel: a cutout of an atlas (it reads the atlas' tiled planar copy) whose axes
+// both have lane tables -- every group of x-tiles inside one 64-column window, every tile of 16 output rows inside
+// four 16-row bands (any scale down to ~1/2.1; deeper shrinks stay with the tile kernel).
+int choose_lane(mic_ctx *ctx, ResizePlan *p, int filter, hipStream_t stream) {
+    p->lane_ok = false;
+    if (!ctx->lane_on || p->atlas < 0) return MIC_OK;
+    FragEntry fh, fv;
+    if (int rc = get_frags(ctx, p->sw, p->dw, filter, stream, &fh, kFragsLaneH)) return rc;
+    if (fh.max_chunks != 1) return MIC_OK;
+    if (int rc = get_frags(ctx, p->sh, p->dh, filter, stream, &fv, kFragsLaneV)) return rc;
+    p->lane_ok = fv.max_chunks == 1;
+    return MIC_OK;
+}
+
+// Cost of a lane piece in shader cycles of one wave among four per SIMD (fitted on the C3 placements call with a
+// cycle-stamp build, scripts/ubench_lane.hip): prologue + bands x (window loads + T horizontal tile passes) + tiles of
+// output rows x (tap fetch, stores + T vertical tile passes and epilogues).  Only the ratios matter: the pieces of a
+// launch are cut so that every wave slot gets the same sum.
+constexpr double kLaneC0 = 7000, kLaneCL = 200, kLaneCH = 1200, kLaneCS = 3500, kLaneCV = 400;
+constexpr double kLaneMinChunk = 45000;  // a slot's work should dwarf a piece's prologue
+
+struct LaneStrip {   // one column strip of a layer: T x-tiles from t0, every tile of output rows
+    size_t plan;
+    int t0, T, ws;
+    FragEntry fh, fv;
+    uint64_t dst;
+};
+
+inline double lane_piece_cost(const std::vector<int32_t> &vm, int T, int y0, int y1) {
+    const int nb = (vm[4 * (y1 - 1) + 1] & 0xFFFFFF) - (vm[4 * y0] >> 4) + 1;
+    return kLaneC0 + nb * (kLaneCL + kLaneCH * T) + (y1 - y0) * (kLaneCS + kLaneCV * T);
+}
+
+// Cut the 1-D sequence of strips x tiles of output rows into at most max_slots chunks of equal cost (a chunk = the
+// pieces of one wave: one piece, or two where the cut falls across the end of a strip), and deal the chunks to the
+// wave slots XCD by XCD: workgroup w runs on XCD w mod 8 (round-robin dispatch, observed), so run k of the chunk
+// sequence goes to workgroups k, k + 8, k + 16, ... -- strips that share source columns, a layer's vertical taps and
+// neighbouring output rows then share an L2 (dealt in launch order the same launch moved 2.4x the bytes over the
+// fabric and took 43 us instead of 35: profiles/r05_lane_kernel.txt).
+void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<LaneStrip> &strips, int min_slots_unused, int max_slots,
+                    PassTables *pt) {
+    (void)min_slots_unused;
+    double total = 0;
+    for (const LaneStrip &s : strips) total += lane_piece_cost(*s.fv.meta_host, s.T, 0, s.fv.tiles);
+    int n_slots = (int)std::min<double>(max_slots, std::max(32.0, total / kLaneMinChunk));
+    n_slots = std::max(32, n_slots / 32 * 32);
+    // every cut re-does up to three bands at the top of the next piece: ~ half a prologue + 2 bands per slot
+    double target = (total + n_slots * (kLaneC0 + 2 * (kLaneCL + 2 * kLaneCH))) / n_slots;
+    std::vector<uint32_t> first;
+    for (int attempt = 0; attempt < 40; ++attempt, target *= 1.03) {
+        pt->lane.clear();
+        first.assign(1, 0u);
+        double acc = 0;
+        for (const LaneStrip &s : strips) {
+            const ResizePlan &p = plans[s.plan];
+            const std::vector<int32_t> &vm = *s.fv.meta_host;
+            const int ty = s.fv.tiles;
+            int y0 = 0;
+            while (y0 < ty) {
+                // the longest piece that still fits the chunk (cost grows with y1: bisection)
+                int lo = y0, hi = ty;  // invariant: [y0, lo) fits (lo == y0: nothing yet), [y0, hi + 1) does not or hi == ty
+                if (acc + lane_piece_cost(vm, s.T, y0, ty) <= target) {
+                    lo = ty;
+                } else {
+                    while (lo < hi) {
+                        const int mid = (lo + hi + 1) / 2;
+                        if (acc + lane_piece_cost(vm, s.T, y0, mid) <= target) lo = mid; else hi = mid - 1;
+                    }
+                }
+                int y1 = lo;
+                if (y1 - y0 < std::min(2, ty - y0)) {
+                    if (acc > 0) {  // does not fit: close the chunk
+                        first.push_back((uint32_t)pt->lane.size());
+                        acc = 0;
+                        continue;
+                    }
+                    y1 = std::min(ty, y0 + 2);  // (an empty chunk takes at least two tiles)
+                }
+                RsLaneUnit u{};
+                u.T = s.T; u.n_vtiles = y1 - y0;
+                u.band0 = vm[4 * y0] >> 4;
+                u.band_last = vm[4 * (y1 - 1) + 1] & 0xFFFFFF;
+                u.plane_bytes = (uint32_t)((size_t)((p.sh + 15) / 16) * p.tiled_ct * 256);
+                u.band_bytes = (uint32_t)(p.tiled_ct * 256);
+                u.src = p.tiled_src + ((uint64_t)u.band0 * p.tiled_ct + s.ws / 16) * 256;
+                u.dst = s.dst;
+                u.hfrag = s.fh.frags + (uint64_t)s.t0 * 3072;
+                u.hbias = s.fh.bias + (uint64_t)s.t0 * 64;
+                u.vfrag = s.fv.frags + (uint64_t)y0 * 3072;
+                u.vbias = s.fv.bias + (uint64_t)y0 * 64;
+                u.vemit = s.fv.meta + ((uint64_t)4 * y0 + 1) * 4;
+                u.x0 = 16 * s.t0; u.row0 = 16 * y0; u.dw = p.dw; u.dh = p.dh;
+                acc += lane_piece_cost(vm, s.T, y0, y1);
+                pt->lane.push_back(u);
+                y0 = y1;
+                if (acc >= 0.97 * target) {
+                    first.push_back((uint32_t)pt->lane.size());
+                    acc = 0;
+                }
+            }
+        }
+        if (first.back() != pt->lane.size()) first.push_back((uint32_t)pt->lane.size());
+        if ((int)first.size() - 1 <= n_slots) break;
+    }
+    const int chunks = (int)first.size() - 1;
+    const int slots = std::max(32, (chunks + 31) / 32 * 32);  // whole workgroups, eight at a time
+    first.resize((size_t)slots + 1, (uint32_t)pt->lane.size());
+    pt->lane_slots = slots;
+    pt->lane_ranges.assign(2 * (size_t)slots, 0u);
+    const int n_wg = slots / 4, per = n_wg / 8;
+    for (int c = 0; c < slots; ++c) {
+        const int k = c / (4 * per), j = c % (4 * per);
+        const int slot = 4 * (8 * (j / 4) + k) + (j % 4);
+        pt->lane_ranges[2 * (size_t)slot] = first[(size_t)c];
+        pt->lane_ranges[2 * (size_t)slot + 1] = first[(size_t)c + 1];
+    }
+}
+
 // Work units the marching kernel would cut a layer into (strips of 4 x-tiles x segments of seg tiles)
 int march_units(const ResizePlan &p, int64_t unit_px, int *seg_tiles_out) {
     const int tiles_x = (p.dw + 15) / 16, tiles_y = (p.dh + 15) / 16;
@@ -860,10 +1059,28 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
     for (const ResizePlan &p : plans)
         if (p.march) march_px += (int64_t)p.dw * p.dh;
     const int64_t unit_px = march_unit_px(march_px);
-    for (const ResizePlan &p : plans) {
+    std::vector<LaneStrip> strips;
+    for (size_t pi = 0; pi < plans.size(); ++pi) {
+        const ResizePlan &p = plans[pi];
         if (p.cached) continue;  // the pixels are in the resident layer cache: no pass
         const bool need_h = p.dw != p.sw, need_v = p.dh != p.sh;
         const uint64_t dst = p.dst_ptr ? p.dst_ptr : arena + p.dst_off;
+        if (p.lane) {
+            LaneStrip st{};
+            if (int rc = get_frags(ctx, p.sw, p.dw, filter, stream, &st.fh, kFragsLaneH)) return rc;
+            if (int rc = get_frags(ctx, p.sh, p.dh, filter, stream, &st.fv, kFragsLaneV)) return rc;
+            pt->frag_refs.push_back(st.fh.buf);
+            pt->frag_refs.push_back(st.fv.buf);
+            st.plan = pi; st.dst = dst;
+            const std::vector<int32_t> &hm = *st.fh.meta_host;
+            for (int t = 0; t < st.fh.tiles; ++t) {
+                if (hm[4 * t + 1] == 0) continue;  // (the second tile of a group)
+                st.t0 = t; st.T = hm[4 * t + 1]; st.ws = hm[4 * t];
+                strips.push_back(st);
+            }
+            ++pt->lane_layers;
+            continue;
+        }
         if (p.march) {
             FragEntry fh, fv;
             if (int rc = get_frags(ctx, p.sw, p.dw, filter, stream, &fh)) return rc;
@@ -944,6 +1161,7 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             pt->max_v_out_h = std::max(pt->max_v_out_h, p.dh);
         }
     }
+    if (!strips.empty()) lane_partition(plans, strips, ctx->lane_min_slots, ctx->lane_max_slots, pt);
     // tile kernel: whole-window entries first, banded ones after (two instantiations, launch_resample_tile)
     auto whole = [](const RsTile &f) { return f.rows16 >= f.pitch_r; };
     pt->tiles_whole = (int)(std::stable_partition(pt->tiles.begin(), pt->tiles.end(), whole) - pt->tiles.begin());
@@ -970,10 +1188,11 @@ struct mic_plan {
     // cutouts whose planar premultiplied copy the marching kernel reads: converted by the first run that finds them
     // unconverted, on that run's stream (the atlases outlive the runs, mic.h)
     std::vector<std::pair<const mic_atlas *, std::vector<int>>> planar_todo;
+    std::vector<std::pair<const mic_atlas *, std::vector<int>>> tiled_todo;  // the same for the lane kernel's tiled copies
     void *scratch = nullptr;   // resampled layers (persistent plans own it; transient ones borrow ctx->arena)
     size_t scratch_bytes = 0;
     void *tables_dev = nullptr;  // persistent plans: jobs | layers | h passes | v passes
-    size_t off_layers = 0, off_f = 0, off_t = 0, off_h = 0, off_v = 0, total = 0;
+    size_t off_layers = 0, off_f = 0, off_t = 0, off_h = 0, off_v = 0, off_lane = 0, off_lane_ranges = 0, total = 0;
     mic_stats stats{};
     // Persistent plans: the job table only depends on the output pointers, so the device copies for
     // the last few sets of outputs are kept (callers rotate over a handful of output sets); a run onto
@@ -1001,7 +1220,9 @@ static void plan_offsets(mic_plan *P) {
     P->off_t = align_up(P->off_f + sizeof(RsMarch) * P->pt.fused.size(), 64);
     P->off_h = align_up(P->off_t + sizeof(RsTile) * P->pt.tiles.size(), 64);
     P->off_v = align_up(P->off_h + sizeof(RsJob) * P->pt.h.size(), 64);
-    P->total = align_up(P->off_v + sizeof(RsJob) * P->pt.v.size(), 64);
+    P->off_lane = align_up(P->off_v + sizeof(RsJob) * P->pt.v.size(), 128);
+    P->off_lane_ranges = align_up(P->off_lane + sizeof(RsLaneUnit) * P->pt.lane.size(), 64);
+    P->total = align_up(P->off_lane_ranges + sizeof(uint32_t) * P->pt.lane_ranges.size(), 64);
 }
 
 // Build the axis tables a call is about to need that the context has not seen -- on several host threads, straight
@@ -1022,7 +1243,7 @@ static void prebuild_axis_frags(mic_ctx *ctx, const std::vector<CoefKey> &keys, 
         if (!pool.run((int)n, [&](int i) {  // phase 1: the coefficient tables (the sin() calls) and the fragment layouts
                 const CoefKey &k = keys[(size_t)i];
                 tables[(size_t)i] = k.filter == -1 ? identity_axis_table(k.in) : build_axis_table(k.in, k.out, k.filter);
-                chunks[(size_t)i] = axis_frags_layout(tables[(size_t)i], &lay[(size_t)i]);
+                chunks[(size_t)i] = axis_frags_layout(tables[(size_t)i], &lay[(size_t)i], k.transposed);
             }))
             return;
         size_t total = 0;
@@ -1062,7 +1283,7 @@ static void prebuild_axis_frags(mic_ctx *ctx, const std::vector<CoefKey> &keys, 
                 char *at = hp + off[i];
                 memcpy(at, lay[i].meta.data(), lay[i].meta.size() * sizeof(int32_t));
                 fill_axis_frags(tables[i], lay[i], reinterpret_cast<int32_t *>(at + meta_b[i]),
-                                reinterpret_cast<int8_t *>(at + meta_b[i] + bias_b[i]), chunks[i]);
+                                reinterpret_cast<int8_t *>(at + meta_b[i] + bias_b[i]), chunks[i], keys[i].transposed);
             }))
             return;
         if (hipMemcpyAsync(dev, hp, total, hipMemcpyHostToDevice, stream) != hipSuccess) { (void)hipGetLastError(); return; }
@@ -1300,6 +1521,7 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                     rp.atlas = Pl.atlas; rp.entry = it->second;
                     if (int rc = choose_march(ctx, &rp, filter, stream)) return rc;
                     if (int rc = choose_tile(ctx, &rp, filter, stream)) return rc;
+                    if (int rc = choose_lane(ctx, &rp, filter, stream)) return rc;
                     plan_idx = plans.size();
                     plans.push_back(rp);
                     dedup.emplace(key, plan_idx);
@@ -1350,6 +1572,38 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
     // the chip (its units are long chains of dependent bands; a few of them are a serial tail) and pays for the
     // cutouts' planar copies, which a persistent plan or a bundle's later calls amortise.  Everything else goes to
     // the tile kernel (reading a planar copy where the atlas already has one) or the two-pass fallback.
+    std::vector<std::vector<std::pair<int, size_t>>> tiled_need((size_t)n_atlases);
+    {   // the lane kernel first: every qualifying layer, once they add up to enough wave slots of work
+        double cost = 0;
+        for (const ResizePlan &rp : plans) {
+            if (!rp.lane_ok || rp.cached) continue;
+            const double tx = (rp.dw + 15) / 16, ty = (rp.dh + 15) / 16, bands = (rp.sh + 15) / 16;
+            cost += tx * (kLaneCH * bands + kLaneCV * ty) + tx / 2 * (kLaneCL * bands + kLaneCS * ty);
+        }
+        const bool use_lane = ctx->lane_on && cost >= kLaneMinChunk * std::max(1, ctx->lane_min_slots);
+        for (size_t i = 0; i < plans.size(); ++i) {
+            ResizePlan &rp = plans[i];
+            rp.lane = rp.lane_ok && use_lane && !rp.cached;
+            if (!rp.lane) continue;
+            rp.march_ok = false;  // (not a candidate for the marching kernel any more)
+            ++P->stats.marched_layers;
+            tiled_need[(size_t)rp.atlas].push_back({rp.entry, i});
+        }
+    }
+    for (int a = 0; a < n_atlases; ++a) {
+        const mic_atlas *A = atlases[a];
+        if (tiled_need[(size_t)a].empty()) continue;
+        std::vector<int> entries;
+        for (const auto &ne : tiled_need[(size_t)a]) entries.push_back(ne.first);
+        if (int rc = atlas_tiled_alloc(A)) return rc;
+        P->tiled_todo.push_back({A, std::move(entries)});
+        for (const auto &ne : tiled_need[(size_t)a]) {
+            ResizePlan &rp = plans[ne.second];
+            rp.tiled_src = reinterpret_cast<uint64_t>(A->tiled->dev) + A->tiled_off[(size_t)rp.entry];
+            rp.tiled_ct = A->tiled_ct[(size_t)rp.entry];
+        }
+        P->pt.frag_refs.push_back(A->tiled);  // the pieces point into it
+    }
     {
         int64_t px = 0;
         for (const ResizePlan &rp : plans)
@@ -1404,6 +1658,12 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
         if (!P->pt.v.empty())
             HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_v, P->pt.v.data(),
                               sizeof(RsJob) * P->pt.v.size(), hipMemcpyHostToDevice));
+        if (!P->pt.lane.empty()) {
+            HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_lane, P->pt.lane.data(),
+                              sizeof(RsLaneUnit) * P->pt.lane.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_lane_ranges, P->pt.lane_ranges.data(),
+                              sizeof(uint32_t) * P->pt.lane_ranges.size(), hipMemcpyHostToDevice));
+        }
     }
     return MIC_OK;
 }
@@ -1511,7 +1771,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         Slot *slot = nullptr;
         if (P->persistent && one) {
             dp = static_cast<char *>(P->tables_dev);
-        } else if (pack_layers && P->pt.fused.empty() && P->pt.tiles.empty() && P->pt.h.empty() && P->pt.v.empty()) {
+        } else if (pack_layers && P->pt.fused.empty() && P->pt.tiles.empty() && P->pt.h.empty() && P->pt.v.empty() && P->pt.lane.empty()) {
             // one canvas, <= 64 identity-scale layers (the reference's own call, compositor.py:6-22 from the Flex
             // pipeline): job AND layer records ride in the kernel arguments -- nothing is staged, nothing uploaded
             static char nothing[64];
@@ -1532,6 +1792,10 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
             if (!P->pt.tiles.empty()) memcpy(hp + P->off_t, P->pt.tiles.data(), sizeof(RsTile) * P->pt.tiles.size());
             if (!P->pt.h.empty()) memcpy(hp + P->off_h, P->pt.h.data(), sizeof(RsJob) * P->pt.h.size());
             if (!P->pt.v.empty()) memcpy(hp + P->off_v, P->pt.v.data(), sizeof(RsJob) * P->pt.v.size());
+            if (!P->pt.lane.empty()) {
+                memcpy(hp + P->off_lane, P->pt.lane.data(), sizeof(RsLaneUnit) * P->pt.lane.size());
+                memcpy(hp + P->off_lane_ranges, P->pt.lane_ranges.data(), sizeof(uint32_t) * P->pt.lane_ranges.size());
+            }
         }
         HIP_TRY(hipMemcpyAsync(upload_dst, slot->host, upload, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipEventRecord(slot->ev, stream));
@@ -1551,6 +1815,12 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         if (missing)
             if (int rc = atlas_planar_build(todo.first, todo.second, stream)) return rc;
     }
+    for (const auto &todo : P->tiled_todo) {
+        bool missing = false;
+        for (int e : todo.second) missing |= !todo.first->tiled_built[(size_t)e];
+        if (missing)
+            if (int rc = atlas_tiled_build(todo.first, todo.second, stream)) return rc;
+    }
     const bool prof = ctx->profiling && ctx->prof_calls < ctx->prof_max && (ctx->prof_seen++ % ctx->prof_every) == 0;
     hipEvent_t *pe = prof ? &ctx->prof_events[(size_t)ctx->prof_calls * 3] : nullptr;
     if (prof) HIP_TRY(hipEventRecord(pe[0], stream));
@@ -1559,6 +1829,9 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     // a persistent plan that has run before finds its resampled layers in its own scratch: composite only
     const bool resident = P->persistent && P->resampled_valid;
     if (!resident) {
+        if (P->pt.lane_slots > 0 && !P->pt.lane.empty())
+            HIP_TRY(launch_resample_lane(reinterpret_cast<const RsLaneUnit *>(dp + P->off_lane),
+                                         reinterpret_cast<const uint32_t *>(dp + P->off_lane_ranges), P->pt.lane_slots, stream));
         HIP_TRY(launch_resample_march(fused_dev, (int)P->pt.fused.size(), P->pt.lds_march, stream));
         HIP_TRY(launch_resample_tile(reinterpret_cast<const RsTile *>(dp + P->off_t), (int)P->pt.tiles.size(),
                                       P->pt.tiles_whole, P->pt.tiles_lds, stream));

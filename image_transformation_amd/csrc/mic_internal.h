@@ -165,6 +165,33 @@ static_assert(sizeof(PlanarJob) == 32, "PlanarJob layout");
 hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream);
 hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_resample_tile(const RsTile *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes, hipStream_t stream);
+// One WAVE's work in the lane kernel (kernels_resample_lane.hip): T adjacent tiles of 16 output columns whose taps fit
+// one 64-column window of the cutout's TILED planar copy, marched from band band0 to band_last, emitting n_vtiles tiles
+// of 16 output rows.  Everything a wave needs first is in the record: scalar loads, then one round of vector loads.
+// Units come in workgroups of four (same layer, same columns: the horizontal fragments are shared through LDS); a
+// padding unit has n_vtiles == 0.
+struct alignas(16) RsLaneUnit {
+    uint64_t src;        // plane 0 of the tiled planar copy, at tile (band0, first window tile)
+    uint64_t dst;        // the layer's pixels (row-major RGBA, dw x dh)
+    uint64_t hfrag;      // [T][3][64][16]: horizontal tap digits of the unit's x-tiles against ITS window
+    uint64_t hbias;      // [T][16] int32
+    uint64_t vfrag;      // [n_vtiles][3][64][16]: vertical tap digits in ring order (band b at k bytes 4 (b & 3) .. + 3)
+    uint64_t vbias;      // [n_vtiles][16] int32
+    uint64_t vemit;      // [n_vtiles] int32: band after which the tile can be emitted | ring words it reads << 24
+    uint32_t plane_bytes, band_bytes;  // bytes between planes / between bands of tiles
+    int32_t band0, band_last;
+    int32_t n_vtiles, T;
+    int32_t x0, row0;    // first output column / row of the unit
+    int32_t dw, dh;
+    int32_t pad[8];
+};
+static_assert(sizeof(RsLaneUnit) == 128, "RsLaneUnit layout");
+#ifndef MIC_RS_LANE_WAVES
+#define MIC_RS_LANE_WAVES 4  // waves per SIMD the lane kernel's register budget is set for
+#endif
+hipError_t launch_resample_lane(const RsLaneUnit *units_dev, const uint32_t *first_dev, int n_slots, hipStream_t stream);
+// PlanarJob with pitch = 16 * (tiles per band) and dst = 4 planes of ceil(h / 16) bands of tiles
+hipError_t launch_planarize_tiled(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream);
 // Known-answer canary of the clip / pack / (un)premultiply helpers (kernels_resample.hip): 0 mismatches expected.
 hipError_t run_selftest_clip(hipStream_t stream, int *mismatches, int *first_bad);
 hipError_t launch_fill(void *out, uint32_t rgba, size_t n_px, hipStream_t stream);

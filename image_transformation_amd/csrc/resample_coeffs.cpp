@@ -74,17 +74,65 @@ AxisTable identity_axis_table(int size) {
     return t;
 }
 
-size_t axis_frags_layout(const AxisTable &t, AxisFrags *f) {
+namespace {
+// first tap / one past the last tap of the 16 outputs of a tile
+inline void tile_span(const AxisTable &t, int tile, int *lo_out, int *hi_out) {
+    const int o0 = tile * 16, o1 = std::min(t.out_size, o0 + 16);
+    int lo = t.bounds[2 * o0], hi = lo;
+    for (int o = o0; o < o1; ++o) {
+        lo = std::min(lo, t.bounds[2 * o]);
+        hi = std::max(hi, t.bounds[2 * o] + t.bounds[2 * o + 1]);
+    }
+    *lo_out = lo;
+    *hi_out = hi;
+}
+}  // namespace
+
+size_t axis_frags_layout(const AxisTable &t, AxisFrags *f, int form) {
     f->tiles = (t.out_size + 15) / 16;
     f->max_chunks = 0;
     f->meta.assign(static_cast<size_t>(f->tiles) * 4, 0);
     size_t chunks = 0;
+    if (form == kFragsLaneH) {
+        for (int tile = 0; tile < f->tiles;) {
+            int lo, hi;
+            tile_span(t, tile, &lo, &hi);
+            const int ws = lo & ~15;
+            int n = 1;
+            if (hi - ws <= 64 && tile + 1 < f->tiles) {
+                int lo2, hi2;
+                tile_span(t, tile + 1, &lo2, &hi2);
+                if (hi2 - ws <= 64) n = 2;
+            }
+            for (int j = 0; j < n; ++j) {
+                int lo_j, hi_j;
+                tile_span(t, tile + j, &lo_j, &hi_j);
+                const int n_chunks = std::max(1, (hi_j - ws + 63) / 64);  // (> 1 only for a lone tile with a wide window)
+                f->meta[4 * (tile + j) + 0] = ws;
+                f->meta[4 * (tile + j) + 1] = j == 0 ? n : 0;
+                f->meta[4 * (tile + j) + 2] = static_cast<int32_t>(chunks);
+                f->meta[4 * (tile + j) + 3] = hi_j;
+                f->max_chunks = std::max(f->max_chunks, n_chunks);
+                chunks += 1;  // one fragment per tile, whatever: a disqualified axis is never read in this form
+            }
+            tile += n;
+        }
+        return chunks;
+    }
     for (int tile = 0; tile < f->tiles; ++tile) {
-        const int o0 = tile * 16, o1 = std::min(t.out_size, o0 + 16);
-        int lo = t.bounds[2 * o0], hi = lo;
-        for (int o = o0; o < o1; ++o) {
-            lo = std::min(lo, t.bounds[2 * o]);
-            hi = std::max(hi, t.bounds[2 * o] + t.bounds[2 * o + 1]);
+        int lo, hi;
+        tile_span(t, tile, &lo, &hi);
+        if (form == kFragsLaneV) {
+            const int b_first = lo >> 4, b_last = (hi - 1) >> 4;
+            int need = 0;
+            for (int b = b_first; b <= b_last; ++b) need |= 1 << (b & 3);
+            f->meta[4 * tile + 0] = lo;
+            f->meta[4 * tile + 1] = b_last | (need << 24);
+            f->meta[4 * tile + 2] = static_cast<int32_t>(chunks);
+            f->meta[4 * tile + 3] = hi;
+            f->max_chunks = std::max(f->max_chunks, b_last - b_first > 3 ? 2 : 1);
+            chunks += 1;
+            continue;
         }
         const int ws = lo & ~15;
         const int n_chunks = std::max(1, (hi - ws + 63) / 64);
@@ -98,9 +146,10 @@ size_t axis_frags_layout(const AxisTable &t, AxisFrags *f) {
     return chunks;
 }
 
-void fill_axis_frags(const AxisTable &t, const AxisFrags &f, int32_t *bias, int8_t *frags, size_t chunks_total) {
+void fill_axis_frags(const AxisTable &t, const AxisFrags &f, int32_t *bias, int8_t *frags, size_t chunks_total, int form) {
     std::fill(bias, bias + static_cast<size_t>(f.tiles) * 16, 0);
     std::fill(frags, frags + chunks_total * 3 * 64 * 16, 0);
+    const bool lane = form == kFragsLaneH || form == kFragsLaneV;
     for (int tile = 0; tile < f.tiles; ++tile) {
         const int o0 = tile * 16, o1 = std::min(t.out_size, o0 + 16);
         const int ws = f.meta[4 * tile + 0];
@@ -116,10 +165,17 @@ void fill_axis_frags(const AxisTable &t, const AxisFrags &f, int32_t *bias, int8
                 const int32_t c1 = (c - d0) >> 8;
                 const int32_t d1 = ((c1 + 128) & 255) - 128;
                 const int32_t d2 = (c1 - d1) >> 8;  // |c| < 2^23 keeps it a signed byte
-                const int pos = first + k - ws;     // window position of this tap
-                const int chunk = pos / 64, h = (pos % 64) / 16, j = pos % 16;
-                const int lane = 16 * h + (o - o0);
-                int8_t *base = &frags[((chunks + chunk) * 3 * 64 + lane) * 16 + j];
+                int chunk, h, j;
+                if (form == kFragsLaneV) {
+                    const int r = first + k;  // absolute source row: ring word (r >> 4) & 3 of lane quarter (r & 15) >> 2
+                    chunk = 0; h = (r & 15) >> 2; j = 4 * ((r >> 4) & 3) + (r & 3);
+                } else {
+                    const int pos = first + k - ws;  // window position of this tap
+                    chunk = pos / 64; h = (pos % 64) / 16; j = pos % 16;
+                }
+                if (lane && chunk > 0) continue;  // (a disqualified axis: its table is never read in this form)
+                const int lane_i = 16 * h + (o - o0);
+                int8_t *base = &frags[((chunks + chunk) * 3 * 64 + lane_i) * 16 + j];
                 base[0 * 64 * 16] = static_cast<int8_t>(d0);
                 base[1 * 64 * 16] = static_cast<int8_t>(d1);
                 base[2 * 64 * 16] = static_cast<int8_t>(d2);
@@ -129,12 +185,12 @@ void fill_axis_frags(const AxisTable &t, const AxisFrags &f, int32_t *bias, int8
     }
 }
 
-AxisFrags build_axis_frags(const AxisTable &t) {
+AxisFrags build_axis_frags(const AxisTable &t, int form) {
     AxisFrags f;
-    const size_t chunks = axis_frags_layout(t, &f);
+    const size_t chunks = axis_frags_layout(t, &f, form);
     f.bias.resize(static_cast<size_t>(f.tiles) * 16);
     f.frags.resize(chunks * 3 * 64 * 16);
-    fill_axis_frags(t, f, f.bias.data(), f.frags.data(), chunks);
+    fill_axis_frags(t, f, f.bias.data(), f.frags.data(), chunks, form);
     return f;
 }
 

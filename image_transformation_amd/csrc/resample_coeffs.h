@@ -32,12 +32,25 @@ struct AxisFrags {
     std::vector<int32_t> bias;
     std::vector<int8_t> frags;
 };
-AxisFrags build_axis_frags(const AxisTable &t);
 // The same in two steps, for callers that place the fragments themselves (several axes into one upload buffer):
 // axis_frags_layout fills tiles / max_chunks / meta and returns the number of 64-tap chunks (frags = chunks * 3072 bytes);
 // fill_axis_frags writes bias[tiles * 16] and frags[chunks * 3072] (which it zeroes first) for that layout.
-size_t axis_frags_layout(const AxisTable &t, AxisFrags *layout);
-void fill_axis_frags(const AxisTable &t, const AxisFrags &layout, int32_t *bias, int8_t *frags, size_t chunks);
+// `form` selects what the fragments are laid out for:
+//   kFragsTile   the marching / tile kernels: every tile against its own window (start = first tap rounded down to 16),
+//                as many 64-tap chunks as the window needs;
+//   kFragsLaneH  the lane kernel's horizontal axis (kernels_resample_lane.hip): tiles are GROUPED, up to two adjacent
+//                tiles whose taps fit one 64-column window share it (the window loads of a band serve both);
+//                meta = {window start of the tile's group, tiles in the group (0 on a group's second tile), chunk, end};
+//                a tile whose own window exceeds 64 columns takes two chunks, which disqualifies the axis (max_chunks);
+//   kFragsLaneV  the lane kernel's vertical axis: a tile's window is the FOUR 16-row bands that end with the band of
+//                its last tap row, and window row r sits at k position 16 ((r & 15) >> 2) + 4 ((r >> 4) & 3) + (r & 3) --
+//                band b lives in word b & 3 of the lane's ring of intermediate rows, rows 4 q .. 4 q + 3 of a band in
+//                lane quarter q; meta = {first tap row, last band | ring words read << 24, chunk, end}; a tile whose
+//                taps span more than four bands disqualifies the axis (max_chunks = 2).
+enum : int { kFragsTile = 0, kFragsLaneH = 2, kFragsLaneV = 3 };
+AxisFrags build_axis_frags(const AxisTable &t, int form = kFragsTile);
+size_t axis_frags_layout(const AxisTable &t, AxisFrags *layout, int form = kFragsTile);
+void fill_axis_frags(const AxisTable &t, const AxisFrags &layout, int32_t *bias, int8_t *frags, size_t chunks, int form = kFragsTile);
 std::vector<int32_t> transpose_coeffs(const AxisTable &t);  // -> [ksize][out_size]
 void thumbnail_size(int w, int h, int req_w, int req_h, int *out_w, int *out_h);
 

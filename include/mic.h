@@ -95,7 +95,13 @@ int mic_atlas_blob_layout(int n, const int32_t *ids, const int32_t *widths, cons
 /* Wrap a device blob (layout above; e.g. received by an RCCL broadcast).  The atlas does not
  * own the memory: the caller keeps it alive until mic_atlas_destroy.  `header_host` may pass
  * the first 32 + 32*n bytes of the blob (header + table) if the caller has them on the host,
- * otherwise NULL and the header is read back from the device.                              */
+ * otherwise NULL and the header is read back from the device.
+ * The blob is IMMUTABLE while the atlas exists (as the cutouts of load_object_images are between the reference's
+ * iterations): libmic derives and keeps data from it -- planar premultiplied copies of cutouts that get resampled,
+ * resampled layers in persistent plans and in the context's layer cache (1.9) -- and cannot see a caller rewriting
+ * the bytes in place.  A caller that must refresh the pixels destroys the atlas and wraps the blob again (a new
+ * atlas is a new cache identity; plans built on the old one are rebuilt), or, for pixels that only identity-scale
+ * placements read, calls mic_plan_invalidate / mic_layer_cache_clear.                                              */
 int mic_atlas_from_device_blob(mic_ctx *ctx, const void *blob_dev, size_t bytes,
                                const void *header_host, mic_atlas **out);
 int mic_atlas_device_blob(const mic_atlas *atlas, const void **blob_dev, size_t *bytes);

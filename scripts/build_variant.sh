@@ -23,5 +23,5 @@ done
 cd "$tmp/image_transformation_amd/csrc"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
   -mllvm -amdgpu-mfma-vgpr-form "${flags[@]}" -o "$root/build/var_$name.bin" mic_api.hip kernels_composite.hip kernels_resample.hip \
-  kernels_resample_tile.hip kernels_median.hip kernels_overlay.hip resample_coeffs.cpp flex_place.cpp png_encode.cpp png_decode.cpp
+  kernels_resample_lane.hip kernels_resample_tile.hip kernels_median.hip kernels_overlay.hip resample_coeffs.cpp flex_place.cpp png_encode.cpp png_decode.cpp
 echo "built build/var_$name.bin"

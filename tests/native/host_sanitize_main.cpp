@@ -75,6 +75,60 @@ int main() {
             }
         }
     }
+    // the lane kernel's forms of the same tables (resample_coeffs.h: kFragsLaneH / kFragsLaneV): where an axis qualifies
+    // (max_chunks == 1) every tap sits at the k position the kernel's operand layout gives its sample, nothing else is
+    // non-zero, groups / emit bands / ring-word masks say what the taps say
+    for (const auto &sh : shapes) {
+        for (int filter = 0; filter < 2; ++filter) {
+            const mic::AxisTable t = sh[0] == sh[1] ? mic::identity_axis_table(sh[0]) : mic::build_axis_table(sh[0], sh[1], filter);
+            for (const int form : {(int)mic::kFragsLaneH, (int)mic::kFragsLaneV}) {
+                const mic::AxisFrags f = mic::build_axis_frags(t, form);
+                if ((int)f.frags.size() != f.tiles * 3072) { fprintf(stderr, "lane form: one fragment per tile\n"); return 4; }
+                if (f.max_chunks != 1) continue;  // the axis does not qualify: the table is never read in this form
+                for (int tile = 0; tile < f.tiles; ++tile) {
+                    const int32_t *m = &f.meta[4 * tile];
+                    if (m[2] != tile) { fprintf(stderr, "lane form: chunk index\n"); return 4; }
+                    long long nonzero_want = 0, nonzero_got = 0;
+                    int lo = 1 << 30, hi = 0;
+                    for (int o = tile * 16; o < std::min(t.out_size, tile * 16 + 16); ++o) {
+                        const int first = t.bounds[2 * o], n = t.bounds[2 * o + 1];
+                        lo = std::min(lo, first); hi = std::max(hi, first + n);
+                        long long total = 0;
+                        for (int k = 0; k < n; ++k) {
+                            const int r = first + k;
+                            int pos;
+                            if (form == mic::kFragsLaneH) {
+                                pos = r - m[0];  // the GROUP's window start
+                            } else {
+                                pos = 16 * ((r & 15) >> 2) + 4 * ((r >> 4) & 3) + (r & 3);
+                            }
+                            if (pos < 0 || pos >= 64) { fprintf(stderr, "lane form: tap outside the window\n"); return 4; }
+                            const int lane = 16 * (pos / 16) + (o - tile * 16), j = pos % 16;
+                            const int8_t *b = &f.frags[((size_t)tile * 3 * 64 + lane) * 16 + j];
+                            const long long c = b[0] + 256LL * b[64 * 16] + 65536LL * b[2 * 64 * 16];
+                            if (c != t.coeffs[(size_t)o * t.ksize + k]) { fprintf(stderr, "lane form: digits do not rebuild the tap\n"); return 4; }
+                            nonzero_want += (b[0] != 0) + (b[64 * 16] != 0) + (b[2 * 64 * 16] != 0);
+                            total += c;
+                        }
+                        if (f.bias[o] != (int32_t)((1 << 21) + 128 * total)) { fprintf(stderr, "lane form: bias\n"); return 4; }
+                    }
+                    for (size_t k = 0; k < 3072; ++k) nonzero_got += f.frags[(size_t)tile * 3072 + k] != 0;
+                    if (nonzero_got != nonzero_want) { fprintf(stderr, "lane form: stray digits\n"); return 4; }
+                    if (form == mic::kFragsLaneH) {
+                        if (m[0] % 16 != 0 || hi - m[0] > 64 || m[3] != hi) { fprintf(stderr, "lane form: window\n"); return 4; }
+                        if (m[1] < 0 || m[1] > 2 || (m[1] == 2 && (tile + 1 >= f.tiles || f.meta[4 * (tile + 1) + 1] != 0 || f.meta[4 * (tile + 1)] != m[0])) ||
+                            (m[1] == 0 && (tile == 0 || f.meta[4 * (tile - 1) + 1] != 2))) { fprintf(stderr, "lane form: groups\n"); return 4; }
+                    } else {
+                        int need = 0;
+                        for (int b = lo >> 4; b <= (hi - 1) >> 4; ++b) need |= 1 << (b & 3);
+                        if (m[0] != lo || m[3] != hi || (m[1] & 0xFFFFFF) != ((hi - 1) >> 4) || (m[1] >> 24) != need || ((hi - 1) >> 4) - (lo >> 4) > 3) {
+                            fprintf(stderr, "lane form: emit band / ring words\n"); return 4; }
+                    }
+                    sum += (uint64_t)nonzero_got;
+                }
+            }
+        }
+    }
     printf("ok=%d unsupported=%d malformed=%d checksum=%llu\n", ok, unsupported, malformed, (unsigned long long)sum);
     return 0;
 }
