@@ -272,36 +272,42 @@ hipError_t launch_resample_lane(const RsLaneUnit *units_dev, const uint32_t *fir
 // Four planes (R, G, B, A premultiplied, stored as signed bytes s - 128) of `bands` x `ct` tiles of 16 rows x 16 columns
 // (256 bytes, row-major inside a tile), tiles ordered band by band; columns >= w and rows >= h hold premultiplied
 // zeros.  ct = ceil(w / 16) + 3, so that the 4-tile window that starts at any tile of a row stays inside the band.
-// One thread = 4 columns of one row (one word per plane), as planarize_kernel.
+// One thread = one row of one tile (16 pixels in, 16 bytes per plane out); consecutive threads are consecutive rows of a
+// tile, so 16 threads write the tile's 256 bytes of a plane back to back.
 __global__ __launch_bounds__(256) void planarize_tiled_kernel(const PlanarJob *__restrict__ jobs) {
     const PlanarJob J = jobs[blockIdx.y];
     const int ct = J.pitch >> 4;           // tiles per band (pitch = 16 ct bytes of columns)
-    const int groups = J.pitch >> 2;       // groups of 4 columns per row
-    const int rows = (J.h + 15) & ~15;
+    const int bands = (J.h + 15) >> 4;
     const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (item >= (int64_t)groups * rows) return;
-    const int y = (int)(item / groups), x = 4 * (int)(item - (int64_t)y * groups);
-    uint32_t px[4];
-    gcptr src = reinterpret_cast<gcptr>(J.src) + (size_t)y * J.w + x;
+    if (item >= (int64_t)bands * ct * 16) return;
+    const int row = (int)(item & 15), tile = (int)(item >> 4);
+    const int band = tile / ct, tx = tile - band * ct;
+    const int y = 16 * band + row, x0 = 16 * tx;
+    gcptr src = reinterpret_cast<gcptr>(J.src) + (size_t)y * J.w + x0;
+    u32x4 out[4];  // [plane] 16 bytes = 16 columns
 #pragma unroll
-    for (int j = 0; j < 4; ++j) px[j] = (y < J.h && x + j < J.w) ? src[j] : 0u;
-    uint32_t rb[4], ga[4];
+    for (int g = 0; g < 4; ++g) {
+        uint32_t px[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t a = px[j] >> 24;
-        rb[j] = premultiply2_hi(px[j] & 0x00FF00FFu, a);
-        ga[j] = premultiply2_hi(byte_perm(px[j], px[j], 0x0c0d0c01u), a);
+        for (int j = 0; j < 4; ++j) px[j] = (y < J.h && x0 + 4 * g + j < J.w) ? src[4 * g + j] : 0u;
+        uint32_t rb[4], ga[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t a = px[j] >> 24;
+            rb[j] = premultiply2_hi(px[j] & 0x00FF00FFu, a);
+            ga[j] = premultiply2_hi(byte_perm(px[j], px[j], 0x0c0d0c01u), a);
+        }
+        const uint32_t rb01 = byte_perm(rb[1], rb[0], 0x07030501u), rb23 = byte_perm(rb[3], rb[2], 0x07030501u);
+        const uint32_t ga01 = byte_perm(ga[1], ga[0], 0x07030501u), ga23 = byte_perm(ga[3], ga[2], 0x07030501u);
+        out[0][g] = byte_perm(rb23, rb01, 0x05040100u) ^ 0x80808080u;  // R
+        out[1][g] = byte_perm(ga23, ga01, 0x05040100u) ^ 0x80808080u;  // G
+        out[2][g] = byte_perm(rb23, rb01, 0x07060302u) ^ 0x80808080u;  // B
+        out[3][g] = byte_perm(ga23, ga01, 0x07060302u) ^ 0x80808080u;  // A
     }
-    const uint32_t rb01 = byte_perm(rb[1], rb[0], 0x07030501u), rb23 = byte_perm(rb[3], rb[2], 0x07030501u);
-    const uint32_t ga01 = byte_perm(ga[1], ga[0], 0x07030501u), ga23 = byte_perm(ga[3], ga[2], 0x07030501u);
-    // tile (band = y >> 4, column tile = x >> 4), row y & 15, byte x & 15
-    const size_t off = ((size_t)(y >> 4) * ct + (x >> 4)) * 256 + (size_t)(y & 15) * 16 + (x & 15);
-    MIC_GLOBAL uint32_t *dst = reinterpret_cast<MIC_GLOBAL uint32_t *>(J.dst + off);
-    const size_t plane = (size_t)(rows >> 4) * ct * 64;  // words
-    dst[0 * plane] = byte_perm(rb23, rb01, 0x05040100u) ^ 0x80808080u;  // R
-    dst[1 * plane] = byte_perm(ga23, ga01, 0x05040100u) ^ 0x80808080u;  // G
-    dst[2 * plane] = byte_perm(rb23, rb01, 0x07060302u) ^ 0x80808080u;  // B
-    dst[3 * plane] = byte_perm(ga23, ga01, 0x07060302u) ^ 0x80808080u;  // A
+    const size_t plane = (size_t)bands * ct * 256;  // bytes
+    MIC_GLOBAL uint8_t *dst = reinterpret_cast<MIC_GLOBAL uint8_t *>(J.dst) + (size_t)tile * 256 + (size_t)row * 16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<MIC_GLOBAL u32x4 *>(dst + c * plane) = out[c];
 }
 
 hipError_t launch_planarize_tiled(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream) {

@@ -10,6 +10,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cerrno>
 #include <climits>
@@ -766,7 +767,7 @@ static int atlas_tiled_build(const mic_atlas *A, const std::vector<int> &need, h
         j.dst = reinterpret_cast<uint64_t>(A->tiled->dev) + A->tiled_off[(size_t)i];
         j.w = e.w; j.h = e.h; j.pitch = 16 * A->tiled_ct[(size_t)i];
         jobs.push_back(j);
-        max_items = std::max<int64_t>(max_items, (int64_t)(j.pitch / 4) * ((e.h + 15) / 16 * 16));
+        max_items = std::max<int64_t>(max_items, (int64_t)(j.pitch / 16) * ((e.h + 15) / 16 * 16));  // rows of tiles
     }
     if (jobs.empty()) return MIC_OK;
     Slot *slot = nullptr;
@@ -962,6 +963,7 @@ void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<Lane
         pt->lane.clear();
         first.assign(1, 0u);
         double acc = 0;
+        const double tgt = target;
         for (const LaneStrip &s : strips) {
             const ResizePlan &p = plans[s.plan];
             const std::vector<int32_t> &vm = *s.fv.meta_host;
@@ -970,12 +972,12 @@ void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<Lane
             while (y0 < ty) {
                 // the longest piece that still fits the chunk (cost grows with y1: bisection)
                 int lo = y0, hi = ty;  // invariant: [y0, lo) fits (lo == y0: nothing yet), [y0, hi + 1) does not or hi == ty
-                if (acc + lane_piece_cost(vm, s.T, y0, ty) <= target) {
+                if (acc + lane_piece_cost(vm, s.T, y0, ty) <= tgt) {
                     lo = ty;
                 } else {
                     while (lo < hi) {
                         const int mid = (lo + hi + 1) / 2;
-                        if (acc + lane_piece_cost(vm, s.T, y0, mid) <= target) lo = mid; else hi = mid - 1;
+                        if (acc + lane_piece_cost(vm, s.T, y0, mid) <= tgt) lo = mid; else hi = mid - 1;
                     }
                 }
                 int y1 = lo;
@@ -1004,7 +1006,7 @@ void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<Lane
                 acc += lane_piece_cost(vm, s.T, y0, y1);
                 pt->lane.push_back(u);
                 y0 = y1;
-                if (acc >= 0.97 * target) {
+                if (acc >= 0.97 * tgt) {
                     first.push_back((uint32_t)pt->lane.size());
                     acc = 0;
                 }
