@@ -216,7 +216,8 @@ struct mic_ctx {
     // kernels (A/B runs, the marching kernel's own tests), MIC_RS_LANE_MIN_SLOTS moves the threshold (0: every
     // qualifying layer), MIC_RS_LANE_SLOTS caps the slots of a launch (default 4096 = 256 CUs x 4 SIMDs x 4 waves).
     bool lane_on = true;
-    int lane_min_slots = 256, lane_max_slots = 4096;
+    int lane_min_slots = 64, lane_max_slots = 1 << 20;
+    double lane_chunk = 15000;  // MIC_RS_LANE_CHUNK: least cost (shader cycles of the model in lane_partition) of one slot's pieces
     uint32_t *median_scratch = nullptr;  // device: two sets of histogram slots (a double buffer) + kMedianMaxBatch result words
     MedianState median_state;            // which half the next call works in, what the previous one left to clear
     bool layer_args = true;              // MIC_LAYER_ARGS=0: single-canvas launches read their layer records from the device table
@@ -315,7 +316,8 @@ extern "C" int mic_create(int device, mic_ctx **out) {
     if (const char *mu = getenv("MIC_RS_MARCH_MIN_UNITS")) ctx->march_min_units = std::max<long long>(0, atoll(mu));
     if (const char *ln = getenv("MIC_RS_LANE")) ctx->lane_on = atoi(ln) != 0;
     if (const char *ln = getenv("MIC_RS_LANE_MIN_SLOTS")) ctx->lane_min_slots = std::max(0, atoi(ln));
-    if (const char *ln = getenv("MIC_RS_LANE_SLOTS")) ctx->lane_max_slots = std::min(65536, std::max(32, atoi(ln) / 32 * 32));
+    if (const char *ln = getenv("MIC_RS_LANE_SLOTS")) ctx->lane_max_slots = std::min(1 << 20, std::max(32, atoi(ln) / 32 * 32));
+    if (const char *ln = getenv("MIC_RS_LANE_CHUNK")) ctx->lane_chunk = std::max(5000.0, atof(ln));
     for (auto &s : ctx->slots) {
         e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
         if (e != hipSuccess) {
@@ -929,7 +931,6 @@ int choose_lane(mic_ctx *ctx, ResizePlan *p, int filter, hipStream_t stream) {
 // output rows x (tap fetch, stores + T vertical tile passes and epilogues).  Only the ratios matter: the pieces of a
 // launch are cut so that every wave slot gets the same sum.
 constexpr double kLaneC0 = 7000, kLaneCL = 200, kLaneCH = 1200, kLaneCS = 3500, kLaneCV = 400;
-constexpr double kLaneMinChunk = 45000;  // a slot's work should dwarf a piece's prologue
 
 struct LaneStrip {   // one column strip of a layer: T x-tiles from t0, every tile of output rows
     size_t plan;
@@ -949,12 +950,20 @@ inline double lane_piece_cost(const std::vector<int32_t> &vm, int T, int y0, int
 // sequence goes to workgroups k, k + 8, k + 16, ... -- strips that share source columns, a layer's vertical taps and
 // neighbouring output rows then share an L2 (dealt in launch order the same launch moved 2.4x the bytes over the
 // fabric and took 43 us instead of 35: profiles/r05_lane_kernel.txt).
-void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<LaneStrip> &strips, int min_slots_unused, int max_slots,
+void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<LaneStrip> &strips, double chunk_cost, int max_slots,
                     PassTables *pt) {
-    (void)min_slots_unused;
     double total = 0;
     for (const LaneStrip &s : strips) total += lane_piece_cost(*s.fv.meta_host, s.T, 0, s.fv.tiles);
-    int n_slots = (int)std::min<double>(max_slots, std::max(32.0, total / kLaneMinChunk));
+    // How many wave slots: small calls are cut fine (chunk_cost, ~2 tiles of output rows: a piece's prologue is half of
+    // that, but such a launch is over in 10-20 us and only parallelism shortens it); once that would exceed the 4096
+    // waves the chip holds at this kernel's occupancy (256 CUs x 4 SIMDs x 4) the launch is WHOLE rounds of 4096 slots
+    // of ~55 K cycles each -- a partial last round is a tail with three quarters of the chip idle (C3 placements canvas:
+    // 38.9 us at 4096 slots, 43-46 at 3 700, 5 500 or 8 800), and within a round neighbouring chunks (which share
+    // source columns and taps through the XCD's L2) run together.  profiles/r05_lane_kernel.txt.
+    constexpr int kRound = 4096;
+    double n = total / chunk_cost;
+    if (n > kRound) n = kRound * std::max(1.0, std::floor(total / (kRound * 55000.0) + 0.5));
+    int n_slots = (int)std::min<double>(max_slots, std::max(32.0, n));
     n_slots = std::max(32, n_slots / 32 * 32);
     // every cut re-does up to three bands at the top of the next piece: ~ half a prologue + 2 bands per slot
     double target = (total + n_slots * (kLaneC0 + 2 * (kLaneCL + 2 * kLaneCH))) / n_slots;
@@ -1163,7 +1172,7 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             pt->max_v_out_h = std::max(pt->max_v_out_h, p.dh);
         }
     }
-    if (!strips.empty()) lane_partition(plans, strips, ctx->lane_min_slots, ctx->lane_max_slots, pt);
+    if (!strips.empty()) lane_partition(plans, strips, ctx->lane_chunk, ctx->lane_max_slots, pt);
     // tile kernel: whole-window entries first, banded ones after (two instantiations, launch_resample_tile)
     auto whole = [](const RsTile &f) { return f.rows16 >= f.pitch_r; };
     pt->tiles_whole = (int)(std::stable_partition(pt->tiles.begin(), pt->tiles.end(), whole) - pt->tiles.begin());
@@ -1582,7 +1591,7 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
             const double tx = (rp.dw + 15) / 16, ty = (rp.dh + 15) / 16, bands = (rp.sh + 15) / 16;
             cost += tx * (kLaneCH * bands + kLaneCV * ty) + tx / 2 * (kLaneCL * bands + kLaneCS * ty);
         }
-        const bool use_lane = ctx->lane_on && cost >= kLaneMinChunk * std::max(1, ctx->lane_min_slots);
+        const bool use_lane = ctx->lane_on && cost >= ctx->lane_chunk * std::max(1, ctx->lane_min_slots);
         for (size_t i = 0; i < plans.size(); ++i) {
             ResizePlan &rp = plans[i];
             rp.lane = rp.lane_ok && use_lane && !rp.cached;

@@ -57,17 +57,21 @@ def _canvas_kinds(rng, sizes):
     return out
 
 
-@pytest.mark.parametrize("march", [False, True])
-def test_composite_batch_over_three_atlases(march, monkeypatch):
+@pytest.mark.parametrize("route", ["tile", "march", "lane"])
+def test_composite_batch_over_three_atlases(route, monkeypatch):
     import torch
     from image_transformation_amd import _native
     from image_transformation_amd.compositor import Atlas, CompositeBatch, coerce_placements, pack_blob
     if not torch.cuda.is_available():
         pytest.fail("-m gpu tests need an MI355X")
+    march = route != "tile"
     rng = np.random.default_rng(77001 + march)
     lib = _native.lib()
-    if march:  # a context whose every qualifying layer takes the marching kernel (planar copies per atlas)
-        monkeypatch.setenv("MIC_RS_MARCH_MIN_UNITS", "0")
+    # a context whose every qualifying layer takes the tile kernel / the marching kernel (planar copies per atlas) /
+    # the lane kernel (tiled planar copies per atlas)
+    for k, v in {"tile": {"MIC_RS_LANE": "0"}, "march": {"MIC_RS_LANE": "0", "MIC_RS_MARCH_MIN_UNITS": "0"},
+                 "lane": {"MIC_RS_LANE_MIN_SLOTS": "0"}}[route].items():
+        monkeypatch.setenv(k, v)
     ctx = _native.Context(torch.cuda.current_device())  # a context of this test's own (mic_create reads the setting)
     bundles = [_bundle(rng, 5, "soft"), _bundle(rng, 7, "binary"), _bundle(rng, 4, "soft")]
     atlases = []

@@ -15,7 +15,9 @@ import cases  # noqa: E402
 import oracle  # noqa: E402
 
 P = ctypes.c_void_p
-KNOBS = ("MIC_RS_MARCH_MIN_UNITS", "MIC_LAYER_CACHE_MB")
+KNOBS = ("MIC_RS_MARCH_MIN_UNITS", "MIC_LAYER_CACHE_MB", "MIC_RS_LANE", "MIC_RS_LANE_MIN_SLOTS")
+# which resample kernel a context routes qualifying layers to (mic_api.hip: routing)
+ROUTES = {"tile": {"MIC_RS_LANE": 0}, "march": {"MIC_RS_LANE": 0, "MIC_RS_MARCH_MIN_UNITS": 0}, "lane": {"MIC_RS_LANE_MIN_SLOTS": 0}}
 
 
 def _ctx(monkeypatch, **env):
@@ -43,15 +45,15 @@ def _scene(rng, n_obj, W, H, n_layers, alpha="soft"):
     return objs, pl
 
 
-@pytest.mark.parametrize("march", [False, True])
-def test_persistent_plans_keep_their_resampled_layers(march, monkeypatch):
+@pytest.mark.parametrize("route", ["tile", "march", "lane"])
+def test_persistent_plans_keep_their_resampled_layers(route, monkeypatch):
     """run 0 resamples, run 1 finds the layers in the plan's scratch (composite only), run 2 follows mic_plan_invalidate
     and resamples again: one canvas per plan (every background kind, aligned and unaligned widths) and nine canvases per
-    plan (shared and private layers, identity-scale layers among them), tile kernel and forced marching kernel."""
+    plan (shared and private layers, identity-scale layers among them); tile kernel, forced marching kernel, forced lane kernel."""
     import torch
     from image_transformation_amd import _native
     from image_transformation_amd.compositor import Atlas, CompositeBatch, SolidCanvas, composite_device, coerce_placements
-    ctx = _ctx(monkeypatch, **({"MIC_RS_MARCH_MIN_UNITS": 0} if march else {}))
+    ctx = _ctx(monkeypatch, **ROUTES[route])
     lib = _native.lib()
     rng = np.random.default_rng(4401)
     W, H = 640, 480
@@ -69,7 +71,7 @@ def test_persistent_plans_keep_their_resampled_layers(march, monkeypatch):
             canvas = SolidCanvas((w, H), (38, 73, 115, 255))
         want = oracle.composite(bg, objs, pl)
         plan = CompositeBatch(atlas, [canvas], [rows])
-        assert (plan.stats()["marched_layers"] >= 8) == march
+        assert (plan.stats()["marched_layers"] >= 8) == (route != "tile")
         for rep in range(3):
             if rep == 2:
                 plan.invalidate()
