@@ -52,10 +52,6 @@ __device__ __forceinline__ V pinned(V v) {
 // hf_lds: this WAVE's own LDS region for the horizontal tap fragments of the piece's x-tiles.
 template <int T>
 __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const float *recip, const int lane) {
-#ifdef MIC_LANE_PROBE
-    const uint64_t pr_t0 = __builtin_amdgcn_s_memtime(), pr_r0 = __builtin_amdgcn_s_memrealtime();
-    uint64_t pr_wait = 0, pr_pro = 0;
-#endif
     const int l15 = lane & 15, lh = lane >> 4;
     const uint32_t lane16 = (uint32_t)lane * 16u, l15x4 = (uint32_t)l15 * 4u;
     const int band0 = pinned(U.band0), band_last = pinned(U.band_last), n_vt = pinned(U.n_vtiles);
@@ -126,15 +122,6 @@ __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const
     auto step = [&](auto PH, const int b) __attribute__((always_inline)) {
         constexpr int q = decltype(PH)::q;
         if (b < band0 || b > band_last) return;  // (wave-uniform)
-#ifdef MIC_LANE_PROBE
-        {
-            const uint64_t w0 = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint64_t w1 = __builtin_amdgcn_s_memtime();
-            pr_wait += w1 - w0;
-            if (b == band0) pr_pro = w1 - pr_t0;
-        }
-#endif
         const v4i a[4] = {A[0], A[1], A[2], A[3]};
         // an all-transparent window (the corners around a cutout's shape): premultiplied zeros in, zeros out
         const int k80 = (int)0x80808080u;
@@ -151,20 +138,14 @@ __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const
             for (int j = 0; j < T; ++j) {
                 const v4i hf[3] = {hf_lds[(j * 3 + 0) * 64 + lane], hf_lds[(j * 3 + 1) * 64 + lane], hf_lds[(j * 3 + 2) * 64 + lane]};
                 uint32_t w[4];
-#ifdef MIC_LANE_NO_H
-                for (int c = 0; c < 4; ++c) w[c] = (uint32_t)(a[c][0] ^ hf[0][c] ^ hbias1[j]);
-#else
                 int hb = hbias1[j];
                 asm volatile("" : "+v"(hb));
                 tile4<true>([&](int c) { return a[c]; }, hf, v4i{hb, hb, hb, hb}, w);
-#endif
 #pragma unroll
                 for (int c = 0; c < 4; ++c) ring[j][c][q] = (int)w[c];
             }
         }
-#ifndef MIC_LANE_NO_LOADS
         if (b < band_last) load_band();
-#endif
         // tiles of output rows whose last tap row is now in the ring
         while (yt < n_vt && (emit & 0xFFFFFF) == b) {
             const uint32_t need = (uint32_t)emit >> 24;
@@ -180,14 +161,8 @@ __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const
                 px[j] = u32x4{0u, 0u, 0u, 0u};
                 if (!all_zero) {
                     uint32_t w[4];
-#ifdef MIC_LANE_NO_V
-                    for (int c = 0; c < 4; ++c) w[c] = (uint32_t)(ring[j][c][0] ^ ring[j][c][1] ^ ring[j][c][2] ^ ring[j][c][3] ^ vf[0][c] ^ vf[1][c] ^ vf[2][c] ^ vb);
-#else
                     tile4<false>([&](int c) { return ring[j][c]; }, vf, v4i{vb, vb, vb, vb}, w);
-#endif
-#ifndef MIC_LANE_NO_LOADS
                     if (j == T - 1) fetch_taps(t_n);
-#endif
                     // alpha bytes all 0 or 255 <=> low 7 bits of every byte equal its top bit
                     const uint32_t top = (w[3] >> 7) & 0x01010101u;
                     const bool soft = (w[3] & 0x7F7F7F7Fu) != (top << 7) - top;
@@ -198,11 +173,7 @@ __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const
             }
 #pragma unroll
             for (int j = 0; j < T; ++j) {
-#ifdef MIC_LANE_NO_STORE
-                const bool inside = row_ok && ox_ok[j] && px[j][0] == 0x12345678u && px[j][3] == 0x9abcdef0u;
-#else
                 const bool inside = row_ok && ox_ok[j];
-#endif
                 if (x_full[j]) {  // (wave-uniform) one 16-byte store per lane
                     if (inside) *reinterpret_cast<MIC_GLOBAL u32x4_a4 *>(dst + o_idx + 16 * j) = px[j];
                 } else if (inside) {
@@ -221,15 +192,6 @@ __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const
         step(Phase<2>{}, b4 + 2);
         step(Phase<3>{}, b4 + 3);
     }
-#ifdef MIC_LANE_PROBE
-    if (lane == 0) {
-        uint64_t *pr = reinterpret_cast<uint64_t *>(*reinterpret_cast<const uint64_t *>(&U.pad[0]));
-        pr[0] = __builtin_amdgcn_s_memtime() - pr_t0;
-        pr[1] = pr_wait;
-        pr[2] = pr_pro | ((__builtin_amdgcn_s_memrealtime() - pr_r0) << 32);  // prologue cycles | piece duration in 10 ns ticks
-        pr[3] = __builtin_amdgcn_s_memrealtime();
-    }
-#endif
 }
 
 }  // namespace
@@ -244,13 +206,6 @@ __global__ __launch_bounds__(256, MIC_RS_LANE_WAVES) void resample_lane_kernel(c
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = (int)blockIdx.x * 4 + wave;
     const uint32_t r0 = first[2 * slot], r1 = first[2 * slot + 1];  // [begin, end) of the slot's pieces
-#ifdef MIC_LANE_STAGGER
-    {   // waves that share a SIMD start in step and stay in step (same program, same step length): their memory waits
-        // coincide and so do their MFMA chains.  Delay each by its wave slot on the SIMD (HW_REG_HW_ID[3:0]).
-        const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));  // HW_ID, offset 0, 4 bits
-        for (uint32_t k = 0; k < (hw & 15u); ++k) __builtin_amdgcn_s_sleep(MIC_LANE_STAGGER);
-    }
-#endif
     recip[tid] = (tid == 0 || tid == 255) ? 1.0f : unpremul_factor((uint32_t)tid);
     __syncthreads();
     for (uint32_t r = r0; r < r1; ++r) {

@@ -3,6 +3,7 @@
 // geometry (x-groups of <= 2 tiles per 64-column window, tiles of output rows emitted after their last band, the
 // equal-cost cut into one chunk of pieces per wave slot), random source bytes and tap digits -- the arithmetic does not
 // depend on the values, only the all-transparent-band shortcut does (never taken on random alpha).
+//   (the ablation / probe builds need the scaffolding: git apply profiles/r05_lane_scaffolding.patch)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I image_transformation_amd/csrc -I include \
 //         -o build/ubench_lane.bin scripts/ubench_lane.hip
 //   build/ubench_lane.bin [slots = 4096] [launches = 50] [binary alpha 0/1] [C0 CL CH CS CV: cost model] [min tiles = 2]
@@ -100,7 +101,8 @@ int main(int argc, char **argv) {
             if (e - f > 3) { fprintf(stderr, "layer %d: vertical window > 4 bands\n", i); return 1; }
             int need = 0;
             for (int b = f; b <= e; ++b) need |= 1 << (b & 3);
-            vemit_host.push_back(e | (need << 24));
+            vemit_host.push_back(e | (need << 24));  // (entries 4 ints apart, as in the library's axis tables: meta rows)
+            vemit_host.push_back(0); vemit_host.push_back(0); vemit_host.push_back(0);
         }
     }
     uint8_t *src, *frag; uint32_t *dst; int32_t *bias, *vemit;
@@ -175,7 +177,7 @@ int main(int argc, char **argv) {
                     u.band_last = (vax[i].hi[y1 - 1] - 1) >> 4;
                     u.vfrag = (uint64_t)(frag + lay[i].vfrag + (size_t)y0 * 3072);
                     u.vbias = (uint64_t)bias;
-                    u.vemit = (uint64_t)(vemit + lay[i].vemit + y0);
+                    u.vemit = (uint64_t)(vemit + lay[i].vemit + 4 * y0);
                     u.src = (uint64_t)(src + lay[i].src + ((size_t)u.band0 * lay[i].ct + ws / 16) * 256);
                     h_passes += (long)(u.band_last - u.band0 + 1) * T;
                     v_passes += (long)u.n_vtiles * T;
