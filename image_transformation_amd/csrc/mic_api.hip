@@ -216,7 +216,7 @@ struct mic_ctx {
     // kernels (A/B runs, the marching kernel's own tests), MIC_RS_LANE_MIN_SLOTS moves the threshold (0: every
     // qualifying layer), MIC_RS_LANE_SLOTS caps the slots of a launch (default 4096 = 256 CUs x 4 SIMDs x 4 waves).
     bool lane_on = true;
-    int lane_min_slots = 64, lane_max_slots = 1 << 20;
+    int lane_min_slots = 256, lane_max_slots = 1 << 20;  // (the reference-sized call, 4 cutouts of ~0.02 Mpx: 67 us of wall through the tile kernel, 80 through this one)
     double lane_chunk = 15000;  // MIC_RS_LANE_CHUNK: least cost (shader cycles of the model in lane_partition) of one slot's pieces
     uint32_t *median_scratch = nullptr;  // device: two sets of histogram slots (a double buffer) + kMedianMaxBatch result words
     MedianState median_state;            // which half the next call works in, what the previous one left to clear
