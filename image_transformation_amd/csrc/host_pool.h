@@ -9,6 +9,8 @@
 #include <thread>
 #include <vector>
 
+#include <unistd.h>
+
 namespace mic {
 
 // A few parked host threads for short parallel loops (the axis tables of a call: 64 x ~60 us).  Starting threads per
@@ -30,7 +32,9 @@ class HostPool {
         fn_ = &fn;
         n_parts_ = n_parts;
         next_ = 0;
-        if (n_parts > 1 && !threads_.empty()) {
+        // A fork()ed child (multiprocessing 'fork', DataLoader workers) inherits this object but none of its threads:
+        // waking them would wait forever.  The loop then runs on the calling thread alone.
+        if (n_parts > 1 && !threads_.empty() && getpid() == owner_) {
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 busy_ = (int)threads_.size();
@@ -48,7 +52,7 @@ class HostPool {
     }
 
   private:
-    HostPool() {
+    HostPool() : owner_(getpid()) {
         const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
         const int n = (int)std::min<unsigned>(15, hw - 1);
         try {
@@ -82,6 +86,7 @@ class HostPool {
         }
     }
     std::vector<std::thread> threads_;
+    const pid_t owner_;  // the process that started the workers
     std::mutex mu_, run_mu_;
     std::condition_variable cv_, done_cv_;
     const std::function<void(int)> *fn_ = nullptr;

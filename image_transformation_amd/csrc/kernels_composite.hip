@@ -225,7 +225,9 @@ template <bool ALIGNED, bool SOLID, int MODE>
 __global__ __launch_bounds__(64 * kPagesPerWorkgroup, (ALIGNED && SOLID) ? MIC_HOT_WAVES : (SOLID ? 6 : 4)) void composite_kernel(
     const Job *__restrict__ jobs, const Layer *__restrict__ layers, const Job one, const LayerPack pack) {
     Job job = MODE != kFromTables ? one : jobs[blockIdx.y];
-    const int page_ = (int)blockIdx.x * kPagesPerWorkgroup + (kPagesPerWorkgroup > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0);
+    // (a small single-job launch comes as one-wave workgroups: kJobOnePagePerWorkgroup in the kernel-argument copy of the job)
+    const int wpb = (MODE != kFromTables && (one.flags & kJobOnePagePerWorkgroup)) ? 1 : kPagesPerWorkgroup;
+    const int page_ = (int)blockIdx.x * wpb + (kPagesPerWorkgroup > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) : 0);
     if (page_ >= job.n_pages) return;
     // A solid colour that lives in device memory (mic_job.bg_rgba_dev: the median kernel's result, consumed without a
     // host round trip): one scalar load, in flight while the layer records are fetched.  The host classes such a job
@@ -499,25 +501,29 @@ hipError_t launch_composite(const Job *jobs_dev, const Layer *layers_dev, int n_
     // for every job of the launch: the XCD <-> page residue pairing survives the 2-D grid.
     const int b[5] = {0, class_end[0], class_end[1], class_end[2], n_jobs};
     if (single && n_jobs == 1) {
-        const dim3 grid(wgs, 1u);
+        const bool small = single->n_pages <= kSmallCanvasPages;
+        const dim3 grid(small ? (unsigned)pitch : wgs, 1u);
+        const dim3 block(small ? 64u : 64u * kPagesPerWorkgroup);
+        if (small && launched_workgroups) *launched_workgroups = (uint64_t)pitch;
         const int cls = b[1] > b[0] ? 0 : b[2] > b[1] ? 1 : b[3] > b[2] ? 2 : 3;
+        Job one = *single;
+        if (small) one.flags |= kJobOnePagePerWorkgroup;
         if (single_layers_host && single->layer_count <= kPackLayers) {
-            Job one = *single;
             if (one.layer_count > 0) memcpy(g_pack.l, single_layers_host + one.layer_begin, sizeof(Layer) * (size_t)one.layer_count);
             one.layer_begin = 0;
             switch (cls) {
-                case 0: hipLaunchKernelGGL((composite_kernel<true, true, kAllInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
-                case 1: hipLaunchKernelGGL((composite_kernel<false, true, kAllInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
-                case 2: hipLaunchKernelGGL((composite_kernel<true, false, kAllInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
-                default: hipLaunchKernelGGL((composite_kernel<false, false, kAllInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+                case 0: hipLaunchKernelGGL((composite_kernel<true, true, kAllInArgs>), grid, block, 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+                case 1: hipLaunchKernelGGL((composite_kernel<false, true, kAllInArgs>), grid, block, 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+                case 2: hipLaunchKernelGGL((composite_kernel<true, false, kAllInArgs>), grid, block, 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+                default: hipLaunchKernelGGL((composite_kernel<false, false, kAllInArgs>), grid, block, 0, stream, jobs_dev, layers_dev, one, g_pack); break;
             }
             return hipGetLastError();
         }
         switch (cls) {
-            case 0: hipLaunchKernelGGL((composite_kernel<true, true, kJobInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
-            case 1: hipLaunchKernelGGL((composite_kernel<false, true, kJobInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
-            case 2: hipLaunchKernelGGL((composite_kernel<true, false, kJobInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
-            default: hipLaunchKernelGGL((composite_kernel<false, false, kJobInArgs>), grid, dim3(64 * kPagesPerWorkgroup), 0, stream, jobs_dev, layers_dev, *single, g_pack); break;
+            case 0: hipLaunchKernelGGL((composite_kernel<true, true, kJobInArgs>), grid, block, 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+            case 1: hipLaunchKernelGGL((composite_kernel<false, true, kJobInArgs>), grid, block, 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+            case 2: hipLaunchKernelGGL((composite_kernel<true, false, kJobInArgs>), grid, block, 0, stream, jobs_dev, layers_dev, one, g_pack); break;
+            default: hipLaunchKernelGGL((composite_kernel<false, false, kJobInArgs>), grid, block, 0, stream, jobs_dev, layers_dev, one, g_pack); break;
         }
         return hipGetLastError();
     }

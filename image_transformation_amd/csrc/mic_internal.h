@@ -14,13 +14,13 @@ typedef const MIC_GLOBAL int32_t *gciptr;
 
 // ---- composite ---------------------------------------------------------------------------
 // The canvas is treated as a linear stream of pixels cut into 4 KiB pages ALIGNED TO ABSOLUTE
-// ADDRESS; one workgroup writes exactly one page.  Measured on MI355X (scripts/streambench.hip,
+// ADDRESS; one WAVE writes exactly one page.  Measured on MI355X (scripts/streambench.hip,
 // 531 MB): a store stream reaches 6.7-6.8 TB/s only when every workgroup, taken in dispatch
 // order, writes one whole 4 KiB page -- workgroups are dealt round-robin over the 8 XCDs, so each
 // XCD then keeps writing one fixed residue class of pages mod 8.  2-D tiles (256 px x 4 rows per
 // wave: 5.5 TB/s), fatter workgroups (8-16 KiB: 6.0), XCD-contiguous ranges (5.0) and grid-stride
 // persistent loops (4.4) all lose; page offset and read-side placement/alignment do not matter.
-// The composite kernel uses one wavefront per page (16 px per lane) so that the per-page work
+// The composite kernel uses one wavefront per page (16 px per lane), four such waves per workgroup, so that the per-page work
 // (one division, layer culling, record broadcast) is amortised over 4 KiB.
 constexpr int kLaneNPx = 4;                    // adjacent pixels per lane per group (16 B)
 constexpr int kWavePx = 64 * kLaneNPx;         // 256 px = 1 KiB per wave-wide access
@@ -49,6 +49,12 @@ struct alignas(16) Job {
     int32_t flags;     // kJobColourWord: the solid colour is read from device memory at `bg` (mic_job.bg_rgba_dev)
 };
 constexpr int32_t kJobColourWord = 1;
+// set by launch_composite on the kernel-argument copy of a single job with at most kSmallCanvasPages pages: the launch
+// uses ONE-wave workgroups (page = workgroup), not kPagesPerWorkgroup-wave ones.  Such a launch is one partial generation of
+// waves; a quarter as many workgroups stops filling the 256 CUs evenly (the 1024 x 328 contact sheet: 88 four-wave
+// workgroups 7.15 - 7.27 us, 336 one-wave ones 6.8 us; 1080p 6.33 against 6.14 - 6.25: profiles/r05_composite_pages_per_workgroup.txt).
+constexpr int32_t kJobOnePagePerWorkgroup = 2;
+constexpr int kSmallCanvasPages = 2048;
 static_assert(sizeof(Job) == 48, "Job layout");
 
 // ---- resample ------------------------------------------------------------------------------

@@ -199,32 +199,37 @@ def _run_layouts(bundle, ratio, flex_layouts, base_out, writer, canvas_size, ori
         writer.text(d0["vlm_input_text"] / "run_metadata.json", meta)
         writer.save(sheet, d0["vlm_input_image"] / "contact_sheet.png")
         writer.copy(bg_path, d0["vlm_input_image"] / "background.png")
-        # (canvas.png needs the colour on the host: written after the loop, when the median kernel has long finished --
-        # asking for it here would be the run's only wait for the GPU before the first draft)
+        # (canvas.png needs the colour on the host: written behind the loop -- in its `finally` --, when the median kernel has
+        # long finished; asking for it here would be the run's only wait for the GPU before the first draft)
 
     drafts: List[Image.Image] = []
     all_placements: List[List[Dict]] = []
-    for i, flex_raw in enumerate(flex_layouts):
-        t0 = time.perf_counter()
-        placements = layout_to_placements(flex_raw, objects, canvas_size)
-        final_json = {
-            "canvas": {"width": canvas_size[0], "height": canvas_size[1], "margin": margin, "align": align},
-            "placements": [{**p, "name": id_to_label.get(int(p["object_id"]), str(int(p["object_id"])))}
-                           for p in placements],
-        }
-        out_dev = composite_device(atlas, [canvas], [coerce_placements(atlas, final_json["placements"])])[0]
-        draft = _to_pil(out_dev, view=True)  # save-only here: a read-only view of the download buffer
-        drafts.append(draft)
-        all_placements.append(final_json["placements"])
+    try:
+        for i, flex_raw in enumerate(flex_layouts):
+            t0 = time.perf_counter()
+            placements = layout_to_placements(flex_raw, objects, canvas_size)
+            final_json = {
+                "canvas": {"width": canvas_size[0], "height": canvas_size[1], "margin": margin, "align": align},
+                "placements": [{**p, "name": id_to_label.get(int(p["object_id"]), str(int(p["object_id"])))}
+                               for p in placements],
+            }
+            out_dev = composite_device(atlas, [canvas], [coerce_placements(atlas, final_json["placements"])])[0]
+            draft = _to_pil(out_dev, view=True)  # save-only here: a read-only view of the download buffer
+            drafts.append(draft)
+            all_placements.append(final_json["placements"])
+            if save:
+                d = _iter_dirs(base_out, i, made)
+                writer.save(draft, d["final_product"] / f"draft_macro_iter_{i:02d}.png")  # (the long one first)
+                writer.text(d["layout_json"] / f"layout_macro_iter_{i:02d}.json", final_json)
+                writer.save(overlay_debug(final_json["placements"], canvas_size),
+                            d["final_product"] / f"overlay_debug_iter_{i:02d}.png")  # :1514, :1700
+                writer.text(d["layout_json"] / f"provenance_iter_{i:02d}.json", {"method": "flex", "fallback": False, "iteration": i})
+            steps.add("compose_baseline" if i == 0 else f"compose_iter_{i:02d}", t0)  # (:1492, :1678)
+    finally:
+        # canvas.png needs the colour on the host (the median kernel has long finished by now: no wait before the first draft).
+        # Written also when an iteration raised -- a bad layout, a full disk -- so that what the output directory holds after a
+        # failure is what the reference leaves there, which writes canvas.png BEFORE its first composite (:1428-1430).
         if save:
-            d = _iter_dirs(base_out, i, made)
-            writer.save(draft, d["final_product"] / f"draft_macro_iter_{i:02d}.png")  # (the long one first)
-            writer.text(d["layout_json"] / f"layout_macro_iter_{i:02d}.json", final_json)
-            writer.save(overlay_debug(final_json["placements"], canvas_size),
-                        d["final_product"] / f"overlay_debug_iter_{i:02d}.png")  # :1514, :1700
-            writer.text(d["layout_json"] / f"provenance_iter_{i:02d}.json", {"method": "flex", "fallback": False, "iteration": i})
-        steps.add("compose_baseline" if i == 0 else f"compose_iter_{i:02d}", t0)  # (:1492, :1678)
-    if save:
-        writer.save(canvas.to_image(), made[0]["vlm_input_image"] / "canvas.png")  # :1428-1430
+            writer.save(canvas.to_image(), made[0]["vlm_input_image"] / "canvas.png")
     return {"canvas_size": canvas_size, "background_rgba": canvas.rgba, "contact_sheet": sheet, "drafts": drafts,
             "placements": all_placements, "output_dir": str(base_out) if base_out else None}

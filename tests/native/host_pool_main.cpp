@@ -7,6 +7,9 @@
 #include <thread>
 #include <vector>
 
+#include <sys/wait.h>
+#include <unistd.h>
+
 #include "host_pool.h"
 
 int main() {
@@ -35,6 +38,19 @@ int main() {
     int one = 0;
     if (!pool.run(1, [&](int) { ++one; }) || one != 1) ++bad;
     if (!pool.run(0, [&](int) { ++one; }) || one != 1) ++bad;
-    printf("workers=%d loops=%ld bad=%ld\n", pool.workers(), loops.load(), bad.load());
+    // a fork()ed child has the pool object but none of its threads: its loops must still complete, on the
+    // calling thread (the child would otherwise wait for workers that do not exist; alarm() turns that into a failure)
+    fflush(stdout);
+    const pid_t child = fork();
+    if (child == 0) {
+        alarm(20);
+        std::atomic<int> parts{0};
+        const bool ok = mic::HostPool::get().run(64, [&](int) { parts.fetch_add(1); });
+        _exit(ok && parts.load() == 64 ? 0 : 3);
+    }
+    int status = -1;
+    if (child < 0 || waitpid(child, &status, 0) != child || !WIFEXITED(status) || WEXITSTATUS(status) != 0) ++bad;
+    printf("workers=%d loops=%ld bad=%ld fork_child=%s\n", pool.workers(), loops.load(), bad.load(),
+           WIFEXITED(status) && WEXITSTATUS(status) == 0 ? "ok" : "FAILED");
     return bad.load() ? 1 : 0;
 }

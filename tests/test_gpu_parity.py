@@ -895,7 +895,8 @@ def test_single_canvas_launch_dispatches_no_surplus_workgroups(gpu):
     that dispatched one four-wave workgroup per PAGE (three quarters of its waves returned at once; results were
     right, so no parity test saw it).  mic_stats.composite_blocks is computed from the grid that is launched: for
     every instantiation (aligned x solid) and both single-job modes (layer records in the kernel arguments: <= 64
-    layers; job only: more) it must cover the canvas' 4 KiB pages with less than one round of 8 workgroups to spare."""
+    layers; job only: more) it must cover the canvas' 4 KiB pages with less than one round of 8 workgroups to spare
+    (workgroups of four pages; of one page for canvases up to 2048 pages, round 5)."""
     import torch
     from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
     syn = cases.synthetic
@@ -926,7 +927,8 @@ def test_single_canvas_launch_dispatches_no_surplus_workgroups(gpu):
                 st = gpu.stats()
                 out_np = out.cpu().numpy()
                 n_pages = (W * H + (out.data_ptr() % 4096) // 4 + 1023) // 1024
-                covered = st["composite_blocks"] * kp
+                # (canvases of at most 2048 pages -- kSmallCanvasPages -- are launched as one-wave workgroups)
+                covered = st["composite_blocks"] * (1 if n_pages <= 2048 else kp)
                 assert n_pages <= covered < n_pages + 8 * kp, ((W, H), solid, n_layers, st["composite_blocks"], n_pages)
                 assert np.array_equal(out_np, oracle.composite(bg_np, objs, pl)), ((W, H), solid, n_layers)
                 seen.add((W % 4 == 0, solid, n_layers <= 64))

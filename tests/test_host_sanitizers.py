@@ -148,7 +148,8 @@ def test_png_huffman_codes_are_complete_and_limited(tmp_path):
 def test_host_pool_under_tsan(tmp_path):
     """csrc/host_pool.h (the parked threads that build a call's axis tables) under ThreadSanitizer: four caller threads
     run 1 200 loops of 1-97 parts on the one pool at once; every part runs exactly once, a throwing part makes run()
-    return false, no race is reported."""
+    return false, no race is reported; a fork()ed child (which has the pool object but none of its threads) still completes
+    its loops."""
     if shutil.which("g++") is None:
         pytest.skip("g++ not available")
     exe = str(tmp_path / "host_pool_tsan")
@@ -161,4 +162,4 @@ def test_host_pool_under_tsan(tmp_path):
     r = subprocess.run([exe], capture_output=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
     assert b"ThreadSanitizer" not in r.stderr and b"data race" not in r.stderr, r.stderr[-3000:]
-    assert r.stdout.strip().endswith(b"bad=0") and b"loops=1200" in r.stdout, r.stdout
+    assert b"bad=0" in r.stdout and b"loops=1200" in r.stdout and b"fork_child=ok" in r.stdout, r.stdout
