@@ -10,6 +10,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <array>
 #include <atomic>
 #include <cerrno>
@@ -302,9 +303,19 @@ extern "C" int mic_create(int device, mic_ctx **out) {
                     e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
     if (device < 0 || device >= count)
         return fail(MIC_ERR_INVALID, "device %d out of range (have %d)", device, count);
+    const bool trace = getenv("MIC_CREATE_TRACE") != nullptr;  // stage times of this call on stderr (bench.py: cold_start)
+    auto t_prev = std::chrono::steady_clock::now();
+    auto tick = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "mic_create: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     HIP_TRY(hipSetDevice(device));
+    tick("hipGetDeviceCount+SetDevice");
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
+    tick("hipGetDeviceProperties");
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(MIC_ERR_NODEVICE, "device %d is %s; libmic is built for gfx950 (MI355X) only", device,
                     prop.gcnArchName);
@@ -325,13 +336,20 @@ extern "C" int mic_create(int device, mic_ctx **out) {
             return fail(MIC_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
         }
     }
+    tick("8 events");
     if (const char *la = getenv("MIC_LAYER_ARGS")) ctx->layer_args = atoi(la) != 0;
     if (const char *v = getenv("MIC_LAYER_CACHE_MB")) ctx->layer_cache_cap = (size_t)std::max(0ll, atoll(v)) << 20;
     if (const char *tl = getenv("MIC_MEDIAN_TWO_LAUNCHES")) ctx->median_two_launches = atoi(tl) != 0 ? 1 : 0;
     e = hipMalloc(&ctx->median_scratch, (kMedianScratchWords + 64) * sizeof(uint32_t));
+    tick("hipMalloc median scratch");
     // zeroed once: every median call clears the half of the double buffer the call before it used
-    if (e == hipSuccess) e = hipMemset(ctx->median_scratch, 0, (kMedianScratchWords + 64) * sizeof(uint32_t));
+    // (with the library's own fill kernel, on the null stream, not waited for: the first hipMemset of a process loads the
+    // runtime's blit kernels -- 85 - 134 ms measured here, most of what a fresh process waited for in mic_create.  Every
+    // entry point orders its stream behind ctx->last_stream (adopt_stream), which starts as the null stream.)
+    if (e == hipSuccess) e = launch_fill(ctx->median_scratch, 0u, kMedianScratchWords + 64, nullptr);
+    tick("zero the median scratch");
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&ctx->median_host), 64, 0);
+    tick("hipHostMalloc 64 B");
     if (e != hipSuccess) {
         mic_destroy(ctx);
         return fail(MIC_ERR_HIP, "context allocation: %s", hipGetErrorString(e));
