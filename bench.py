@@ -726,7 +726,7 @@ def main():
     # measured separately with rocprofv3 (bench.py cannot run under --pmc and time itself) and committed under
     # profiles/; only quoted for the workload they were measured on.
     traffic, traffic_src, rocprof_kernel_ms = None, None, None
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):
             with open(tpath) as f:
@@ -1183,7 +1183,8 @@ def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_
             "ms_per_canvas_wall": round(e2 / 10 * 1e3, 3), "resample_ms": round(r2, 4), "composite_ms": round(c2, 4),
             "Mpixels_per_s": round(W * H * 10 / e2 / 1e6, 1),
             "composite_roofline_frac": frac(plan_bytes(ps), c2),
-            "resample_roofline": {"bound": "instruction issue in the loop (84 % of vector issue at full residency), residency over the launch: profiles/r03_resample_experiments.txt",
+            "resample_roofline": {"bound": "vector instruction issue (the lane kernel, round 5: ~150 vector instructions + 24 MFMA per band and x-tile; the "
+                                           "issue port is busy most of the launch), then the prologue ramp of a one-round launch: profiles/r05_lane_kernel.txt",
                                   "algorithmic_bytes": rs_bytes, "achieved_GBps": round(rs_bytes / (r2 * 1e-3) / 1e9, 1),
                                   "frac_of_hbm_peak": frac(rs_bytes, r2)}}
         if amode == "soft":
@@ -1211,7 +1212,8 @@ def extras(result, args, ctx, atlas, objs, layouts, placements, rows, plan, out_
                 "resample_frac_of_hbm_peak": frac(4 * (bs["source_pixels"] + out_px), r3),
                 "pillow_ms_per_canvas": pillow_ms,
                 "note": "per-canvas times of ONE 16-canvas call (cold: every layer resampled in that call; warm: layers resident); "
-                        "the single-canvas legs above are one generation of waves (8104 one-wave workgroups on 8192 slots) and so ramp-bound"}
+                        "the single-canvas legs above are ONE partial generation of waves (a 4K canvas: 2032 four-wave workgroups = 8128 waves for 8100 pages, "
+                        "on 8192 wave slots at this kernel's occupancy) and so bound by launch + ramp + dependent round trips, not by bandwidth"}
             del bplan, bout
         del pplan, patlas
 

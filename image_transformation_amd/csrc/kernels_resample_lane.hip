@@ -58,7 +58,10 @@ __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const
     const uint32_t band_bytes = pinned(U.band_bytes);
     const uint64_t p0 = pinned(U.src), p1 = pinned(p0 + U.plane_bytes), p2 = pinned(p1 + U.plane_bytes), p3 = pinned(p2 + U.plane_bytes);
     const uint64_t vfrag = pinned(U.vfrag), vbias = pinned(U.vbias);
-    const MIC_GLOBAL int32_t *vemit = reinterpret_cast<const MIC_GLOBAL int32_t *>(pinned(U.vemit));
+    // (constant address space: the table entries are wave-uniform and must come through SCALAR loads -- as a vector load
+    // the next tile's entry was waited for with vmcnt(0) at the head of every tile, behind the band loads just issued)
+    typedef const __attribute__((address_space(4))) int32_t *sciptr;
+    sciptr vemit = reinterpret_cast<sciptr>(pinned(U.vemit));
     // every first load of the piece, issued together: horizontal fragments, the first band, biases, the first tile's taps
     v4i hfc[3 * T];
     {
