@@ -83,11 +83,7 @@ __device__ __forceinline__ u32x4 load4(gcptr p) {
 }
 __device__ __forceinline__ uint32_t load1(gcptr p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void store4(gptr p, u32x4 v) {
-#ifdef MIC_PLAIN_STORES
-    *reinterpret_cast<MIC_GLOBAL u32x4_a4 *>(p) = v;
-#else
     __builtin_nontemporal_store(v, reinterpret_cast<MIC_GLOBAL u32x4_a4 *>(p));
-#endif
 }
 __device__ __forceinline__ void store1(gptr p, uint32_t v) { __builtin_nontemporal_store(v, p); }
 
@@ -149,12 +145,8 @@ __device__ __forceinline__ u32x4 load_tap(const Layer &L, const Tap &t) {
     // Default cache policy on purpose: the atlas is shared by every canvas of a batch and by
     // neighbouring pages, and lives in L2 / the Infinity Cache between uses.  Nontemporal loads here
     // cost 15% of the kernel (C3 batch: 134.7 -> 114.8 us); nontemporal STORES are worth +5%.
-#ifdef MIC_SRC_NT_LOADS
-    return __builtin_nontemporal_load(
-        reinterpret_cast<const MIC_GLOBAL u32x4_a4 *>(basep + (uint32_t)(t.off * 4 + 16)));
-#else
+    // (A/B switches for both policies: profiles/r05_tuning_scaffolding.patch, -DMIC_PLAIN_STORES / -DMIC_SRC_NT_LOADS)
     return *reinterpret_cast<const MIC_GLOBAL u32x4_a4 *>(basep + (uint32_t)(t.off * 4 + 16));
-#endif
 }
 
 // Keep the loaded pixels whose layer column c = t.sx + j satisfies lo <= c < lo + span, zero

@@ -292,12 +292,8 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBat
     // replaces (an L2 write-back and an L1 invalidate, ~1.7 us each) were a third of a small image's time.
     // INVARIANT (checked by tests/test_abi.py::test_median_scratch_is_only_touched_by_atomics): between the LDS clear
     // and this point nothing writes I.hist except atomicAdd; a plain store here would need the fences back.
-    // -DMIC_MEDIAN_FENCES restores the release/acquire pair (bisecting aid).
-#ifdef MIC_MEDIAN_FENCES
-    __atomic_thread_fence(__ATOMIC_RELEASE);  // (agent scope is the default for HIP's fences)
-#else
+    // (profiles/r05_tuning_scaffolding.patch brings the release / acquire pair back behind -DMIC_MEDIAN_FENCES: a bisecting aid)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     __syncthreads();
     if (threadIdx.x == 0) {
         const uint32_t ticket =
@@ -306,9 +302,6 @@ __global__ __launch_bounds__(64 * kHistWaves) void median_kernel(const MedianBat
     }
     __syncthreads();
     if (!is_last) return;
-#ifdef MIC_MEDIAN_FENCES
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
-#endif
     median_select(hist, (int)I.copies, I.out_rgba, wave_tot, res);
     // (the scratch is NOT re-zeroed here: the next call uses the other half of the double buffer and clears this one
     // while its own first loads are in flight)

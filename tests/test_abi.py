@@ -78,7 +78,8 @@ def test_median_scratch_is_only_touched_by_atomics():
     for m in re.finditer(r"\b(hist|hist_copy)\s*(\[[^\]]*\])?\s*(\[[^\]]*\])?\s*([-+|&^]?=)(?!=)", body):
         line = body[body.rfind("\n", 0, m.start()) + 1:body.find("\n", m.end())]
         assert re.search(r"uint32_t \*hist(_copy)? =", line), f"plain store to the median scratch: {line.strip()}"
-    assert "atomicAdd(reinterpret_cast<unsigned long long *>(&hist_copy[" in body and "MIC_MEDIAN_FENCES" in body
+    assert "atomicAdd(reinterpret_cast<unsigned long long *>(&hist_copy[" in body
+    assert 's_waitcnt vmcnt(0)' in body  # what stands in for the release fence in front of the ticket
 
 
 def test_host_only_entry_points(built_lib):
