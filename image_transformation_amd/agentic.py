@@ -13,7 +13,7 @@ identity-size subset of compositor.composite, which is pinned.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Any, Dict, List, Mapping, Tuple
+from typing import Any, Dict, Mapping, Tuple
 
 from PIL import Image
 
@@ -45,54 +45,84 @@ class PlacementState:
         self.y += delta
 
 
-def _non_negative(value: int, label: str) -> int:
+def _spacing(node: Mapping, key: str) -> int:
+    """`gap_px` / `padding_px` of a container: int() of whatever the JSON holds (so "7" is 7 and "x", None or [1] raise
+    int()'s own ValueError / TypeError), negative values refused with the reference's message."""
+    value = int(node.get(key, 0))
     if value < 0:
-        raise ValueError(f"{label} cannot be negative")
+        raise ValueError(f"{key} cannot be negative")
     return value
-
-
-def _place(node: Dict, origin: Tuple[int, int], objects: Mapping[int, ObjectMeta],
-           out: Dict[int, PlacementState]) -> Tuple[int, int]:
-    """Place `node` with its top-left corner at `origin`; returns its (w, h).  Children are packed
-    from the start of the main axis and NOT aligned on the cross axis (agentic/utils/layout.py:55-104)."""
-    if "object_id" in node:
-        oid = int(node["object_id"])
-        meta = objects[oid]  # KeyError for unknown ids, as in the reference
-        out[oid] = PlacementState(object_id=oid, name=meta.name, x=origin[0], y=origin[1],
-                                  width=meta.width, height=meta.height)
-        return meta.width, meta.height
-    direction = node.get("direction")
-    gap = _non_negative(int(node.get("gap_px", 0)), "gap_px")
-    pad = _non_negative(int(node.get("padding_px", 0)), "padding_px")
-    children = node.get("children", [])
-    if not children:
-        raise ValueError("container must have at least one child")
-    x, y = origin[0] + pad, origin[1] + pad
-    sizes: List[Tuple[int, int]] = []
-    for child in children:
-        w, h = _place(child, (x, y), objects, out)
-        sizes.append((w, h))
-        if direction == "row":
-            x += w + gap
-        else:
-            y += h + gap
-    if direction == "row":
-        total = (sum(s[0] for s in sizes) + gap * (len(sizes) - 1), max(s[1] for s in sizes))
-    else:
-        total = (max(s[0] for s in sizes), sum(s[1] for s in sizes) + gap * (len(sizes) - 1))
-    return total[0] + 2 * pad, total[1] + 2 * pad
 
 
 def placements_from_flex(flex: Dict, canvas_size: Tuple[int, int],
                          objects: Mapping[int, ObjectMeta]) -> Dict[int, PlacementState]:
-    """agentic/utils/layout.py:106-121: place from (0,0); reject layouts larger than the canvas and
-    layouts that miss an object.  (A bad `direction` only raises where the reference's measure
-    helper would be reached; the place helper treats any non-"row" value as a column, as there.)"""
+    """agentic/utils/layout.py:52-121 (`_place_node` + `placements_from_flex`): children are packed from the start of the
+    main axis, NOT aligned on the cross axis, the whole tree starts at (0, 0); a layout larger than the canvas or one
+    that misses an object is refused.  (A bad `direction` never raises here: anything that is not "row" is a column,
+    as in the reference's place helper.)
+
+    The reference recurses; this walks the tree with an explicit stack of open containers, which visits the nodes --
+    and therefore meets the errors, and fills the result dict -- in the same order: a container's gap and padding are
+    read when it is opened (gap first), an empty one raises right then, a leaf looks its object up when it is reached
+    (KeyError for an unknown id), a later leaf with the same id replaces the earlier entry in place."""
     if "root" not in flex:
         raise ValueError("Flex JSON must include 'root'")
     out: Dict[int, PlacementState] = {}
-    w, h = _place(flex["root"], (0, 0), objects, out)
-    if w > canvas_size[0] or h > canvas_size[1]:
+
+    class _Open:  # one container being filled: where its next child goes, what its children add up to so far
+        __slots__ = ("row", "gap", "pad", "todo", "x", "y", "main", "cross", "count")
+
+        def __init__(self, node: Mapping, x: int, y: int):
+            self.row = node.get("direction") == "row"
+            self.gap = _spacing(node, "gap_px")
+            self.pad = _spacing(node, "padding_px")
+            children = node.get("children", [])
+            if not children:
+                raise ValueError("container must have at least one child")
+            self.todo = iter(children)
+            self.x, self.y = x + self.pad, y + self.pad
+            self.main = self.cross = self.count = 0
+
+        def add(self, w: int, h: int) -> None:  # a finished child of size (w, h): advance the cursor along the main axis
+            along, across = (w, h) if self.row else (h, w)
+            self.main += along
+            self.cross = max(self.cross, across)
+            self.count += 1
+            if self.row:
+                self.x += w + self.gap
+            else:
+                self.y += h + self.gap
+
+        def size(self) -> Tuple[int, int]:
+            main = self.main + self.gap * (self.count - 1) + 2 * self.pad
+            cross = self.cross + 2 * self.pad
+            return (main, cross) if self.row else (cross, main)
+
+    def leaf(node: Mapping, x: int, y: int) -> Tuple[int, int]:
+        oid = int(node["object_id"])
+        meta = objects[oid]
+        out[oid] = PlacementState(object_id=oid, name=meta.name, x=x, y=y, width=meta.width, height=meta.height)
+        return meta.width, meta.height
+
+    root = flex["root"]
+    if "object_id" in root:
+        total = leaf(root, 0, 0)
+    else:
+        stack = [_Open(root, 0, 0)]
+        total = (0, 0)
+        while stack:
+            top = stack[-1]
+            child = next(top.todo, None)
+            if child is None:  # every child placed: the container's own size goes to its parent
+                stack.pop()
+                total = top.size()
+                if stack:
+                    stack[-1].add(*total)
+            elif "object_id" in child:
+                top.add(*leaf(child, top.x, top.y))
+            else:
+                stack.append(_Open(child, top.x, top.y))
+    if total[0] > canvas_size[0] or total[1] > canvas_size[1]:
         raise ValueError("Flex DSL produces placements larger than canvas; revise macro layout")
     missing = set(objects.keys()) - set(out.keys())
     if missing:
