@@ -949,6 +949,12 @@ int choose_lane(mic_ctx *ctx, ResizePlan *p, int filter, hipStream_t stream) {
 // output rows x (tap fetch, stores + T vertical tile passes and epilogues).  Only the ratios matter: the pieces of a
 // launch are cut so that every wave slot gets the same sum.
 constexpr double kLaneC0 = 7000, kLaneCL = 200, kLaneCH = 1200, kLaneCS = 3500, kLaneCV = 400;
+// the same for a whole layer, from its sizes alone (two x-tiles per strip assumed): what decides whether a call is big
+// enough for the lane kernel before any table exists
+inline double lane_layer_cost(int sh, int dw, int dh) {
+    const double tx = (dw + 15) / 16, ty = (dh + 15) / 16, bands = (sh + 15) / 16;
+    return tx * (kLaneCH * bands + kLaneCV * ty) + tx / 2 * (kLaneCL * bands + kLaneCS * ty);
+}
 
 struct LaneStrip {   // one column strip of a layer: T x-tiles from t0, every tile of output rows
     size_t plan;
@@ -970,6 +976,9 @@ inline double lane_piece_cost(const std::vector<int32_t> &vm, int T, int y0, int
 // fabric and took 43 us instead of 35: profiles/r05_lane_kernel.txt).
 void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<LaneStrip> &strips, double chunk_cost, int max_slots,
                     PassTables *pt) {
+    static const bool trace = getenv("MIC_LANE_TRACE") != nullptr;  // one line per launch on stderr (tuning)
+    const auto t_begin = std::chrono::steady_clock::now();
+    int attempts = 0;
     double total = 0;
     for (const LaneStrip &s : strips) total += lane_piece_cost(*s.fv.meta_host, s.T, 0, s.fv.tiles);
     // How many wave slots: small calls are cut fine (chunk_cost, ~2 tiles of output rows: a piece's prologue is half of
@@ -984,9 +993,12 @@ void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<Lane
     int n_slots = (int)std::min<double>(max_slots, std::max(32.0, n));
     n_slots = std::max(32, n_slots / 32 * 32);
     // every cut re-does up to three bands at the top of the next piece: ~ half a prologue + 2 bands per slot
-    double target = (total + n_slots * (kLaneC0 + 2 * (kLaneCL + 2 * kLaneCH))) / n_slots;
+    // (+ 3 %: what the greedy cut loses at chunk ends; with it the first pass nearly always fits -- a pass is ~100 us of host time)
+    double target = 1.03 * (total + n_slots * (kLaneC0 + 2 * (kLaneCL + 2 * kLaneCH))) / n_slots;
     std::vector<uint32_t> first;
+    pt->lane.reserve((size_t)n_slots + n_slots / 4 + strips.size());
     for (int attempt = 0; attempt < 40; ++attempt, target *= 1.03) {
+        ++attempts;
         pt->lane.clear();
         first.assign(1, 0u);
         double acc = 0;
@@ -997,15 +1009,17 @@ void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<Lane
             const int ty = s.fv.tiles;
             int y0 = 0;
             while (y0 < ty) {
-                // the longest piece that still fits the chunk (cost grows with y1: bisection)
-                int lo = y0, hi = ty;  // invariant: [y0, lo) fits (lo == y0: nothing yet), [y0, hi + 1) does not or hi == ty
+                // the longest piece that still fits the chunk: cost grows with y1, nearly linearly -- start from the
+                // tile count the strip's average cost per tile row predicts and walk (a step or two) to the exact answer
+                int lo = y0;  // [y0, lo) fits (lo == y0: nothing yet)
                 if (acc + lane_piece_cost(vm, s.T, y0, ty) <= tgt) {
                     lo = ty;
                 } else {
-                    while (lo < hi) {
-                        const int mid = (lo + hi + 1) / 2;
-                        if (acc + lane_piece_cost(vm, s.T, y0, mid) <= tgt) lo = mid; else hi = mid - 1;
-                    }
+                    const double per_tile = (kLaneCS + kLaneCV * s.T) + (kLaneCL + kLaneCH * s.T) * ((p.sh + 15) / 16) / (double)ty;
+                    const double room = tgt - acc - kLaneC0 - 2 * (kLaneCL + kLaneCH * s.T);
+                    lo = std::min(ty - 1, std::max(y0, y0 + (int)(room / per_tile)));
+                    while (lo > y0 && acc + lane_piece_cost(vm, s.T, y0, lo) > tgt) --lo;
+                    while (lo < ty - 1 && acc + lane_piece_cost(vm, s.T, y0, lo + 1) <= tgt) ++lo;
                 }
                 int y1 = lo;
                 if (y1 - y0 < std::min(2, ty - y0)) {
@@ -1054,6 +1068,10 @@ void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<Lane
         pt->lane_ranges[2 * (size_t)slot] = first[(size_t)c];
         pt->lane_ranges[2 * (size_t)slot + 1] = first[(size_t)c + 1];
     }
+    if (trace)
+        fprintf(stderr, "lane_partition: %zu strips, model cost %.0f, %d slots asked, %d chunks, %zu pieces, %d pass(es), %.0f us\n",
+                strips.size(), total, n_slots, chunks, pt->lane.size(), attempts,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
 }
 
 // Work units the marching kernel would cut a layer into (strips of 4 x-tiles x segments of seg tiles)
@@ -1463,6 +1481,29 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
     // per atlas: (entry, plan) of the cutouts this call runs through the marching resample kernel
     std::vector<std::vector<std::pair<int, size_t>>> planar_need((size_t)std::max(n_atlases, 1));
 
+    // Is this a call for the lane kernel?  Decided up front on the boxes alone (the same estimate the routing below
+    // confirms with the tables in hand), because it says which FORM of the axis tables to build: the lane forms for such
+    // a call, the tile forms otherwise -- never both for the same never-seen box size (a table is ~60 us of sin()).
+    bool lane_call = false;
+    if (ctx->lane_on) {
+        double cost = 0;
+        for (int ji = 0; ji < n_jobs; ++ji) {
+            const mic_job &J = jobs[ji];
+            if (J.n_placements <= 0 || !J.placements) continue;
+            for (int pi = 0; pi < J.n_placements; ++pi) {
+                const mic_placement &Pl = J.placements[pi];
+                if (Pl.atlas < 0 || Pl.atlas >= n_atlases) continue;
+                const mic_atlas *A = atlases[Pl.atlas];
+                auto it = A->index.find(Pl.object_id);
+                if (it == A->index.end()) continue;
+                const BlobEntry &E = A->entries[it->second];
+                const int64_t w = std::max<int64_t>(1, (int64_t)Pl.box[2] - Pl.box[0]), h = std::max<int64_t>(1, (int64_t)Pl.box[3] - Pl.box[1]);
+                if ((w == E.w && h == E.h) || w > kMaxDim || h > kMaxDim) continue;
+                cost += lane_layer_cost(E.h, (int)w, (int)h);  // (a box placed twice counts twice: an estimate)
+            }
+        }
+        lane_call = cost >= ctx->lane_chunk * std::max(1, ctx->lane_min_slots);
+    }
     {   // the axis tables of this call's resized boxes that the context has not seen yet, built ahead on several threads
         std::vector<CoefKey> need;
         std::map<CoefKey, int> listed;
@@ -1478,7 +1519,8 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                 const BlobEntry &E = A->entries[it->second];
                 const int64_t w = std::max<int64_t>(1, (int64_t)Pl.box[2] - Pl.box[0]), h = std::max<int64_t>(1, (int64_t)Pl.box[3] - Pl.box[1]);
                 if ((w == E.w && h == E.h) || w > kMaxDim || h > kMaxDim) continue;
-                const CoefKey kx{E.w, (int)w, E.w == (int)w ? -1 : filter, 0}, ky{E.h, (int)h, E.h == (int)h ? -1 : filter, 0};
+                const CoefKey kx{E.w, (int)w, E.w == (int)w ? -1 : filter, lane_call ? (int)kFragsLaneH : (int)kFragsTile},
+                    ky{E.h, (int)h, E.h == (int)h ? -1 : filter, lane_call ? (int)kFragsLaneV : (int)kFragsTile};
                 for (const CoefKey &k : {kx, ky})
                     if (!ctx->frags.count(k) && listed.emplace(k, 1).second) need.push_back(k);
             }
@@ -1548,9 +1590,12 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                     rp.src = reinterpret_cast<uint64_t>(A->blob) + E.offset;
                     rp.sw = E.w; rp.sh = E.h; rp.dw = (int)w; rp.dh = (int)h;
                     rp.atlas = Pl.atlas; rp.entry = it->second;
-                    if (int rc = choose_march(ctx, &rp, filter, stream)) return rc;
-                    if (int rc = choose_tile(ctx, &rp, filter, stream)) return rc;
-                    if (int rc = choose_lane(ctx, &rp, filter, stream)) return rc;
+                    if (lane_call)
+                        if (int rc = choose_lane(ctx, &rp, filter, stream)) return rc;
+                    if (!rp.lane_ok) {  // (a layer the lane kernel does not take, or a small call: the tile forms)
+                        if (int rc = choose_march(ctx, &rp, filter, stream)) return rc;
+                        if (int rc = choose_tile(ctx, &rp, filter, stream)) return rc;
+                    }
                     plan_idx = plans.size();
                     plans.push_back(rp);
                     dedup.emplace(key, plan_idx);
@@ -1602,17 +1647,11 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
     // cutouts' planar copies, which a persistent plan or a bundle's later calls amortise.  Everything else goes to
     // the tile kernel (reading a planar copy where the atlas already has one) or the two-pass fallback.
     std::vector<std::vector<std::pair<int, size_t>>> tiled_need((size_t)n_atlases);
-    {   // the lane kernel first: every qualifying layer, once they add up to enough wave slots of work
-        double cost = 0;
-        for (const ResizePlan &rp : plans) {
-            if (!rp.lane_ok || rp.cached) continue;
-            const double tx = (rp.dw + 15) / 16, ty = (rp.dh + 15) / 16, bands = (rp.sh + 15) / 16;
-            cost += tx * (kLaneCH * bands + kLaneCV * ty) + tx / 2 * (kLaneCL * bands + kLaneCS * ty);
-        }
-        const bool use_lane = ctx->lane_on && cost >= ctx->lane_chunk * std::max(1, ctx->lane_min_slots);
+    {   // the lane kernel first: every qualifying layer of a call that was sized for it above (what is left of such a
+        // call once the resident layers are taken out goes the same way: its tables exist in the lane forms only)
         for (size_t i = 0; i < plans.size(); ++i) {
             ResizePlan &rp = plans[i];
-            rp.lane = rp.lane_ok && use_lane && !rp.cached;
+            rp.lane = rp.lane_ok && lane_call && !rp.cached;
             if (!rp.lane) continue;
             rp.march_ok = false;  // (not a candidate for the marching kernel any more)
             ++P->stats.marched_layers;
