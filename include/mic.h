@@ -337,7 +337,9 @@ typedef struct mic_stats {
     uint64_t identity_layers;
     uint64_t skipped_placements;  /* unknown ids                                           */
     uint64_t composite_blocks;    /* workgroups launched by the composite kernel           */
-    uint64_t marched_layers;      /* of resampled_layers: those run by the marching resample kernel (1.5) */
+    uint64_t marched_layers;      /* of resampled_layers: those run by the big-call MFMA resample kernels -- the lane
+                                   * kernel (round 5), or the marching kernel under MIC_RS_LANE=0 -- rather than by the
+                                   * tile kernel / two-pass fallback (1.5)                                            */
     uint64_t cached_layers;       /* of the call's distinct resampled layers: found in the resident cache (1.9) */
 } mic_stats;
 int mic_last_stats(const mic_ctx *ctx, mic_stats *out);
