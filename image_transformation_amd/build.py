@@ -124,8 +124,26 @@ def check_isa(verbose: bool = False) -> None:
                                "v_ashr_pk_u8_i32 fusion (which ORs a stale upper half, ROCm 7.2) is back: see clip8")
     if march[0].count("v_ashr_pk_u8_i32") < 8 or march[0].count("v_ashr_pk_i8_i32") < 8:
         raise RuntimeError("check_isa: the marching kernel's epilogues lost their v_ashr_pk_{u8,i8}_i32 (clip8x4)")
+    # the lane kernel (round 5) uses the same helpers (resample_mfma.h); it must not spill either: its register budget
+    # (118 of the 128 VGPRs that four waves per SIMD allow) is what its structure was chosen for
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "lane.s")
+        subprocess.check_call([hipcc(), f"--offload-arch={ARCH}"] + flags + ["-S", "--cuda-device-only", "-o", out,
+                                                                               os.path.join(CSRC, "kernels_resample_lane.hip")],
+                              stderr=subprocess.DEVNULL)
+        with open(out, encoding="utf-8", errors="replace") as f:
+            text = f.read()
+    m = re.search(r"^(_ZN3mic20resample_lane_kernel\w+):.*?\n(.*?)s_endpgm", text, re.S | re.M)
+    if not m:
+        raise RuntimeError("check_isa: resample_lane_kernel not found in the assembly")
+    lane = m.group(2)
+    if lane.count("v_ashr_pk_u8_i32") < 16 or lane.count("v_ashr_pk_i8_i32") < 16 or lane.count("v_mfma_i32_16x16x64_i8") < 96:
+        raise RuntimeError("check_isa: the lane kernel lost its MFMA chains / v_ashr_pk_{u8,i8}_i32 epilogues")
+    if "scratch_" in lane:
+        raise RuntimeError("check_isa: the lane kernel spills to scratch (its band loop then waits on scratch traffic: 62 us measured)")
     if verbose:
-        print("check_isa ok: two-pass kernels clamp with v_med3_i32, MFMA epilogues use v_ashr_pk_{u8,i8}_i32 via the builtin")
+        print("check_isa ok: two-pass kernels clamp with v_med3_i32, MFMA epilogues use v_ashr_pk_{u8,i8}_i32 via the builtin, "
+              "the lane kernel does not spill")
 
 
 if __name__ == "__main__":
