@@ -62,13 +62,7 @@ __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const
     // the next tile's entry was waited for with vmcnt(0) at the head of every tile, behind the band loads just issued)
     typedef const __attribute__((address_space(4))) int32_t *sciptr;
     sciptr vemit = reinterpret_cast<sciptr>(pinned(U.vemit));
-    // every first load of the piece, issued together: horizontal fragments, the first band, biases, the first tile's taps
-    v4i hfc[3 * T];
-    {
-        gv4ptr hfb = at<v4i>(U.hfrag, lane16);
-#pragma unroll
-        for (int i = 0; i < 3 * T; ++i) hfc[i] = hfb[64 * i];
-    }
+    // every first load of the piece, issued together: the first band, horizontal fragments, biases, the first tile's taps
     uint32_t voff = lane16;  // this lane's 16 bytes of the next band to load (same offset in every plane)
     // ONE set of operand registers: the next band is requested as soon as the horizontal pass has issued its last
     // MFMA on this one, and lands behind the vertical tiles of the step (a second set costs 16 registers: spills)
@@ -81,6 +75,12 @@ __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const
         voff += band_bytes;
     };
     load_band();
+    v4i hfc[3 * T];
+    {
+        gv4ptr hfb = at<v4i>(U.hfrag, lane16);
+#pragma unroll
+        for (int i = 0; i < 3 * T; ++i) hfc[i] = hfb[64 * i];
+    }
 
     // horizontal bias per x-tile (- 128 << 22: the horizontal pass clips to signed bytes, see clip8x4_signed)
     int hb_raw[T];
@@ -199,30 +199,32 @@ __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const
 
 }  // namespace
 
-// One wave = one slot of the launch: it works through its own short list of pieces (usually one; two where the host's
-// equal-cost cut falls across the end of a column strip), records first[2 w] .. first[2 w + 1] - 1.  The four waves of a
+// One wave = one slot of the launch: it works through its own short chain of pieces (usually one; two where the host's
+// equal-cost cut falls across the end of a column strip): record `slot`, then its `next`s.  The four waves of a
 // workgroup share the unpremultiply table and nothing else: one barrier, before any memory is touched.
-__global__ __launch_bounds__(256, MIC_RS_LANE_WAVES) void resample_lane_kernel(const RsLaneUnit *__restrict__ units,
-                                                                               const uint32_t *__restrict__ first) {
+__global__ __launch_bounds__(256, MIC_RS_LANE_WAVES) void resample_lane_kernel(const RsLaneUnit *__restrict__ units) {
     __shared__ v4i hf_lds[4][2 * 3 * 64];  // [wave][x-tile][digit][lane] 16 bytes
     __shared__ float recip[256];           // unpremultiply factors 255 / a: an LDS read per soft pixel
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int slot = (int)blockIdx.x * 4 + wave;
-    const uint32_t r0 = first[2 * slot], r1 = first[2 * slot + 1];  // [begin, end) of the slot's pieces
     recip[tid] = (tid == 0 || tid == 255) ? 1.0f : unpremul_factor((uint32_t)tid);
     __syncthreads();
-    for (uint32_t r = r0; r < r1; ++r) {
+    uint32_t r = (uint32_t)slot;
+    do {
         const RsLaneUnit &U = units[r];
-        if (U.T == 1)
-            lane_run<1>(U, hf_lds[wave], recip, lane);
-        else
-            lane_run<2>(U, hf_lds[wave], recip, lane);
-    }
+        r = U.next;
+        if (U.n_vtiles > 0) {
+            if (U.T == 1)
+                lane_run<1>(U, hf_lds[wave], recip, lane);
+            else
+                lane_run<2>(U, hf_lds[wave], recip, lane);
+        }
+    } while (r != 0u);
 }
 
-hipError_t launch_resample_lane(const RsLaneUnit *units_dev, const uint32_t *first_dev, int n_slots, hipStream_t stream) {
-    if (n_slots <= 0) return hipSuccess;  // (n_slots: a multiple of 4; first_dev: [begin, end) per slot)
-    hipLaunchKernelGGL(resample_lane_kernel, dim3((unsigned)(n_slots / 4)), dim3(256), 0, stream, units_dev, first_dev);
+hipError_t launch_resample_lane(const RsLaneUnit *units_dev, int n_slots, hipStream_t stream) {
+    if (n_slots <= 0) return hipSuccess;  // (n_slots: a multiple of 4; records [0, n_slots) are the slots' first pieces)
+    hipLaunchKernelGGL(resample_lane_kernel, dim3((unsigned)(n_slots / 4)), dim3(256), 0, stream, units_dev);
     return hipGetLastError();
 }
 

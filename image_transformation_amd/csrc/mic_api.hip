@@ -841,8 +841,7 @@ struct PassTables {
     std::vector<RsJob> h, v;
     int max_h_out_w = 0, max_h_rows = 0, max_v_out_w = 0, max_v_out_h = 0;
     // lane kernel: pieces, and per wave slot the [begin, end) of its pieces (slots: a multiple of 32)
-    std::vector<RsLaneUnit> lane;
-    std::vector<uint32_t> lane_ranges;
+    std::vector<RsLaneUnit> lane;  // records [0, lane_slots): first piece per slot; chained pieces behind
     int lane_slots = 0, lane_layers = 0;
 };
 
@@ -1060,16 +1059,27 @@ void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<Lane
     const int slots = std::max(32, (chunks + 31) / 32 * 32);  // whole workgroups, eight at a time
     first.resize((size_t)slots + 1, (uint32_t)pt->lane.size());
     pt->lane_slots = slots;
-    pt->lane_ranges.assign(2 * (size_t)slots, 0u);
+    // records [0, slots): the slots' first pieces (a wave finds its work with ONE scalar load); further pieces of a
+    // chunk follow behind, chained through `next`
+    std::vector<RsLaneUnit> dealt((size_t)slots);
+    dealt.reserve((size_t)slots + pt->lane.size() - (size_t)chunks + 8);
     const int n_wg = slots / 4, per = n_wg / 8;
     for (int c = 0; c < slots; ++c) {
         const int k = c / (4 * per), j = c % (4 * per);
-        const int slot = 4 * (8 * (j / 4) + k) + (j % 4);
-        pt->lane_ranges[2 * (size_t)slot] = first[(size_t)c];
-        pt->lane_ranges[2 * (size_t)slot + 1] = first[(size_t)c + 1];
+        const size_t slot = (size_t)(4 * (8 * (j / 4) + k) + (j % 4));
+        const uint32_t b0 = first[(size_t)c], b1 = first[(size_t)c + 1];
+        if (b0 == b1) continue;  // (an empty slot: the zero record, n_vtiles == 0)
+        dealt[slot] = pt->lane[b0];
+        size_t prev = slot;
+        for (uint32_t r = b0 + 1; r < b1; ++r) {
+            dealt[prev].next = (uint32_t)dealt.size();
+            prev = dealt.size();
+            dealt.push_back(pt->lane[r]);
+        }
     }
+    pt->lane.swap(dealt);
     if (trace)
-        fprintf(stderr, "lane_partition: %zu strips, model cost %.0f, %d slots asked, %d chunks, %zu pieces, %d pass(es), %.0f us\n",
+        fprintf(stderr, "lane_partition: %zu strips, model cost %.0f, %d slots asked, %d chunks, %zu records, %d pass(es), %.0f us\n",
                 strips.size(), total, n_slots, chunks, pt->lane.size(), attempts,
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
 }
@@ -1239,7 +1249,7 @@ struct mic_plan {
     void *scratch = nullptr;   // resampled layers (persistent plans own it; transient ones borrow ctx->arena)
     size_t scratch_bytes = 0;
     void *tables_dev = nullptr;  // persistent plans: jobs | layers | h passes | v passes
-    size_t off_layers = 0, off_f = 0, off_t = 0, off_h = 0, off_v = 0, off_lane = 0, off_lane_ranges = 0, total = 0;
+    size_t off_layers = 0, off_f = 0, off_t = 0, off_h = 0, off_v = 0, off_lane = 0, total = 0;
     mic_stats stats{};
     // Persistent plans: the job table only depends on the output pointers, so the device copies for
     // the last few sets of outputs are kept (callers rotate over a handful of output sets); a run onto
@@ -1268,8 +1278,7 @@ static void plan_offsets(mic_plan *P) {
     P->off_h = align_up(P->off_t + sizeof(RsTile) * P->pt.tiles.size(), 64);
     P->off_v = align_up(P->off_h + sizeof(RsJob) * P->pt.h.size(), 64);
     P->off_lane = align_up(P->off_v + sizeof(RsJob) * P->pt.v.size(), 128);
-    P->off_lane_ranges = align_up(P->off_lane + sizeof(RsLaneUnit) * P->pt.lane.size(), 64);
-    P->total = align_up(P->off_lane_ranges + sizeof(uint32_t) * P->pt.lane_ranges.size(), 64);
+    P->total = align_up(P->off_lane + sizeof(RsLaneUnit) * P->pt.lane.size(), 64);
 }
 
 // Build the axis tables a call is about to need that the context has not seen -- on several host threads, straight
@@ -1726,12 +1735,9 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
         if (!P->pt.v.empty())
             HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_v, P->pt.v.data(),
                               sizeof(RsJob) * P->pt.v.size(), hipMemcpyHostToDevice));
-        if (!P->pt.lane.empty()) {
+        if (!P->pt.lane.empty())
             HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_lane, P->pt.lane.data(),
                               sizeof(RsLaneUnit) * P->pt.lane.size(), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(static_cast<char *>(P->tables_dev) + P->off_lane_ranges, P->pt.lane_ranges.data(),
-                              sizeof(uint32_t) * P->pt.lane_ranges.size(), hipMemcpyHostToDevice));
-        }
     }
     return MIC_OK;
 }
@@ -1860,10 +1866,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
             if (!P->pt.tiles.empty()) memcpy(hp + P->off_t, P->pt.tiles.data(), sizeof(RsTile) * P->pt.tiles.size());
             if (!P->pt.h.empty()) memcpy(hp + P->off_h, P->pt.h.data(), sizeof(RsJob) * P->pt.h.size());
             if (!P->pt.v.empty()) memcpy(hp + P->off_v, P->pt.v.data(), sizeof(RsJob) * P->pt.v.size());
-            if (!P->pt.lane.empty()) {
-                memcpy(hp + P->off_lane, P->pt.lane.data(), sizeof(RsLaneUnit) * P->pt.lane.size());
-                memcpy(hp + P->off_lane_ranges, P->pt.lane_ranges.data(), sizeof(uint32_t) * P->pt.lane_ranges.size());
-            }
+            if (!P->pt.lane.empty()) memcpy(hp + P->off_lane, P->pt.lane.data(), sizeof(RsLaneUnit) * P->pt.lane.size());
         }
         HIP_TRY(hipMemcpyAsync(upload_dst, slot->host, upload, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipEventRecord(slot->ev, stream));
@@ -1898,8 +1901,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     const bool resident = P->persistent && P->resampled_valid;
     if (!resident) {
         if (P->pt.lane_slots > 0 && !P->pt.lane.empty())
-            HIP_TRY(launch_resample_lane(reinterpret_cast<const RsLaneUnit *>(dp + P->off_lane),
-                                         reinterpret_cast<const uint32_t *>(dp + P->off_lane_ranges), P->pt.lane_slots, stream));
+            HIP_TRY(launch_resample_lane(reinterpret_cast<const RsLaneUnit *>(dp + P->off_lane), P->pt.lane_slots, stream));
         HIP_TRY(launch_resample_march(fused_dev, (int)P->pt.fused.size(), P->pt.lds_march, stream));
         HIP_TRY(launch_resample_tile(reinterpret_cast<const RsTile *>(dp + P->off_t), (int)P->pt.tiles.size(),
                                       P->pt.tiles_whole, P->pt.tiles_lds, stream));

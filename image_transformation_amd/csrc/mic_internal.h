@@ -174,8 +174,8 @@ hipError_t launch_resample_tile(const RsTile *jobs_dev, int n_jobs, int n_whole,
 // One WAVE's work in the lane kernel (kernels_resample_lane.hip): T adjacent tiles of 16 output columns whose taps fit
 // one 64-column window of the cutout's TILED planar copy, marched from band band0 to band_last, emitting n_vtiles tiles
 // of 16 output rows.  Everything a wave needs first is in the record: scalar loads, then one round of vector loads.
-// Units come in workgroups of four (same layer, same columns: the horizontal fragments are shared through LDS); a
-// padding unit has n_vtiles == 0.
+// Record s (s < slots) is the first piece of wave slot s (n_vtiles == 0: the slot has nothing to do); the few slots
+// whose equal-cost chunk falls across the end of a strip chain further pieces through `next` (records >= slots).
 struct alignas(16) RsLaneUnit {
     uint64_t src;        // plane 0 of the tiled planar copy, at tile (band0, first window tile)
     uint64_t dst;        // the layer's pixels (row-major RGBA, dw x dh)
@@ -189,13 +189,14 @@ struct alignas(16) RsLaneUnit {
     int32_t n_vtiles, T;
     int32_t x0, row0;    // first output column / row of the unit
     int32_t dw, dh;
-    int32_t pad[8];
+    uint32_t next;       // index of the wave's next piece (0: none) -- records [0, slots) are the slots' FIRST pieces
+    int32_t pad[7];
 };
 static_assert(sizeof(RsLaneUnit) == 128, "RsLaneUnit layout");
 #ifndef MIC_RS_LANE_WAVES
 #define MIC_RS_LANE_WAVES 4  // waves per SIMD the lane kernel's register budget is set for
 #endif
-hipError_t launch_resample_lane(const RsLaneUnit *units_dev, const uint32_t *first_dev, int n_slots, hipStream_t stream);
+hipError_t launch_resample_lane(const RsLaneUnit *units_dev, int n_slots, hipStream_t stream);
 // PlanarJob with pitch = 16 * (tiles per band) and dst = 4 planes of ceil(h / 16) bands of tiles
 hipError_t launch_planarize_tiled(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream);
 // Known-answer canary of the clip / pack / (un)premultiply helpers (kernels_resample.hip): 0 mismatches expected.

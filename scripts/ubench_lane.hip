@@ -201,7 +201,8 @@ int main(int argc, char **argv) {
     // chunk -> slot: XCD-contiguous (workgroup w runs on XCD w mod 8: the chunk sequence is cut into 8 runs, run k goes
     // to the workgroups k, k + 8, k + 16, ...) or in order (XCDMAP=0)
     const bool xcdmap = getenv("XCDMAP") ? atoi(getenv("XCDMAP")) != 0 : true;
-    std::vector<uint32_t> ranges(2 * (size_t)slots_used, 0);
+    // records [0, slots): the slots' first pieces; further pieces of a chunk chained behind through `next` (as the library does)
+    std::vector<RsLaneUnit> dealt((size_t)slots_used);
     {
         const int n_wg = slots_used / 4, per = (n_wg + 7) / 8;  // workgroups per XCD
         for (int c = 0; c < slots_used; ++c) {
@@ -212,12 +213,17 @@ int main(int argc, char **argv) {
                 slot = wg < n_wg ? 4 * wg + (j % 4) : -1;
             }
             if (slot < 0) { fprintf(stderr, "slot map overflow\n"); return 1; }
-            ranges[2 * slot] = first[c]; ranges[2 * slot + 1] = first[c + 1];
+            if (first[c] == first[c + 1]) continue;
+            dealt[slot] = units[first[c]];
+            size_t prev = (size_t)slot;
+            for (uint32_t r = first[c] + 1; r < first[c + 1]; ++r) {
+                dealt[prev].next = (uint32_t)dealt.size();
+                prev = dealt.size();
+                dealt.push_back(units[r]);
+            }
         }
     }
-    uint32_t *first_dev;
-    CK(hipMalloc(&first_dev, ranges.size() * 4));
-    CK(hipMemcpy(first_dev, ranges.data(), ranges.size() * 4, hipMemcpyHostToDevice));
+    units.swap(dealt);
     uint64_t *probe_dev = nullptr;
     CK(hipMalloc(&probe_dev, units.size() * 32));
     CK(hipMemset(probe_dev, 0, units.size() * 32));
@@ -233,12 +239,12 @@ int main(int argc, char **argv) {
     (void)skipped;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int k = 0; k < 5; ++k) CK(launch_resample_lane(units_dev, first_dev, slots_used, 0));
+    for (int k = 0; k < 5; ++k) CK(launch_resample_lane(units_dev, slots_used, 0));
     CK(hipDeviceSynchronize());
     float best = 1e9f, sum = 0;
     for (int k = 0; k < launches; ++k) {
         CK(hipEventRecord(e0, 0));
-        CK(launch_resample_lane(units_dev, first_dev, slots_used, 0));
+        CK(launch_resample_lane(units_dev, slots_used, 0));
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -246,7 +252,7 @@ int main(int argc, char **argv) {
     }
     // back to back (what a stream of calls sees)
     CK(hipEventRecord(e0, 0));
-    for (int k = 0; k < launches; ++k) CK(launch_resample_lane(units_dev, first_dev, slots_used, 0));
+    for (int k = 0; k < launches; ++k) CK(launch_resample_lane(units_dev, slots_used, 0));
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
