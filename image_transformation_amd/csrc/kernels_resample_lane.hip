@@ -245,11 +245,20 @@ __global__ __launch_bounds__(256) void planarize_tiled_kernel(const PlanarJob *_
     const int y = 16 * band + row, x0 = 16 * tx;
     gcptr src = reinterpret_cast<gcptr>(J.src) + (size_t)y * J.w + x0;
     u32x4 out[4];  // [plane] 16 bytes = 16 columns
+    const bool whole = y < J.h && x0 + 16 <= J.w;  // all 16 pixels exist: four 16-byte loads (rows are only 4-byte aligned)
+    u32x4 in[4] = {u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+    if (whole) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) in[g] = *reinterpret_cast<const MIC_GLOBAL u32x4_a4 *>(src + 4 * g);
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) in[g][j] = (y < J.h && x0 + 4 * g + j < J.w) ? src[4 * g + j] : 0u;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        uint32_t px[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) px[j] = (y < J.h && x0 + 4 * g + j < J.w) ? src[4 * g + j] : 0u;
+        const uint32_t px[4] = {in[g][0], in[g][1], in[g][2], in[g][3]};
         uint32_t rb[4], ga[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
