@@ -1064,9 +1064,10 @@ void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<Lane
     std::vector<RsLaneUnit> dealt((size_t)slots);
     dealt.reserve((size_t)slots + pt->lane.size() - (size_t)chunks + 8);
     const int n_wg = slots / 4, per = n_wg / 8;
+    static const bool in_order = [] { const char *e = getenv("MIC_RS_LANE_XCDMAP"); return e && atoi(e) == 0; }();  // (A/B: chunk c -> slot c)
     for (int c = 0; c < slots; ++c) {
         const int k = c / (4 * per), j = c % (4 * per);
-        const size_t slot = (size_t)(4 * (8 * (j / 4) + k) + (j % 4));
+        const size_t slot = in_order ? (size_t)c : (size_t)(4 * (8 * (j / 4) + k) + (j % 4));
         const uint32_t b0 = first[(size_t)c], b1 = first[(size_t)c + 1];
         if (b0 == b1) continue;  // (an empty slot: the zero record, n_vtiles == 0)
         dealt[slot] = pt->lane[b0];
