@@ -17,7 +17,7 @@ LIB = os.path.join(HERE, "libmic.so")
 SOURCES = ["mic_api.hip", "kernels_composite.hip", "kernels_resample.hip", "kernels_resample_lane.hip", "kernels_resample_tile.hip", "kernels_median.hip",
            "kernels_overlay.hip",
            "resample_coeffs.cpp", "flex_place.cpp", "png_encode.cpp", "png_decode.cpp"]
-HEADERS = ["mic_internal.h", "resample_mfma.h", "resample_coeffs.h", "flex_place.h", "png_encode.h", "png_decode.h", "png_checksum.h", "host_pool.h", os.path.join("..", "..", "include", "mic.h")]
+HEADERS = ["mic_internal.h", "lane_unit.h", "lane_partition.h", "resample_mfma.h", "resample_coeffs.h", "flex_place.h", "png_encode.h", "png_decode.h", "png_checksum.h", "host_pool.h", os.path.join("..", "..", "include", "mic.h")]
 ARCH = "gfx950"
 
 

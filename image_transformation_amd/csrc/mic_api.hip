@@ -32,6 +32,7 @@
 
 #include "../../include/mic.h"  // declares mic_plan, mic_ctx, mic_atlas
 #include "mic_internal.h"
+#include "lane_partition.h"
 #include "flex_place.h"
 #include "host_pool.h"
 #include "png_decode.h"
@@ -943,148 +944,6 @@ int choose_lane(mic_ctx *ctx, ResizePlan *p, int filter, hipStream_t stream) {
     return MIC_OK;
 }
 
-// Cost of a lane piece in shader cycles of one wave among four per SIMD (fitted on the C3 placements call with a
-// cycle-stamp build, scripts/ubench_lane.hip): prologue + bands x (window loads + T horizontal tile passes) + tiles of
-// output rows x (tap fetch, stores + T vertical tile passes and epilogues).  Only the ratios matter: the pieces of a
-// launch are cut so that every wave slot gets the same sum.
-constexpr double kLaneC0 = 7000, kLaneCL = 200, kLaneCH = 1200, kLaneCS = 3500, kLaneCV = 400;
-// the same for a whole layer, from its sizes alone (two x-tiles per strip assumed): what decides whether a call is big
-// enough for the lane kernel before any table exists
-inline double lane_layer_cost(int sh, int dw, int dh) {
-    const double tx = (dw + 15) / 16, ty = (dh + 15) / 16, bands = (sh + 15) / 16;
-    return tx * (kLaneCH * bands + kLaneCV * ty) + tx / 2 * (kLaneCL * bands + kLaneCS * ty);
-}
-
-struct LaneStrip {   // one column strip of a layer: T x-tiles from t0, every tile of output rows
-    size_t plan;
-    int t0, T, ws;
-    FragEntry fh, fv;
-    uint64_t dst;
-};
-
-inline double lane_piece_cost(const std::vector<int32_t> &vm, int T, int y0, int y1) {
-    const int nb = (vm[4 * (y1 - 1) + 1] & 0xFFFFFF) - (vm[4 * y0] >> 4) + 1;
-    return kLaneC0 + nb * (kLaneCL + kLaneCH * T) + (y1 - y0) * (kLaneCS + kLaneCV * T);
-}
-
-// Cut the 1-D sequence of strips x tiles of output rows into at most max_slots chunks of equal cost (a chunk = the
-// pieces of one wave: one piece, or two where the cut falls across the end of a strip), and deal the chunks to the
-// wave slots XCD by XCD: workgroup w runs on XCD w mod 8 (round-robin dispatch, observed), so run k of the chunk
-// sequence goes to workgroups k, k + 8, k + 16, ... -- strips that share source columns, a layer's vertical taps and
-// neighbouring output rows then share an L2 (dealt in launch order the same launch moved 2.4x the bytes over the
-// fabric and took 43 us instead of 35: profiles/r05_lane_kernel.txt).
-void lane_partition(const std::vector<ResizePlan> &plans, const std::vector<LaneStrip> &strips, double chunk_cost, int max_slots,
-                    PassTables *pt) {
-    static const bool trace = getenv("MIC_LANE_TRACE") != nullptr;  // one line per launch on stderr (tuning)
-    const auto t_begin = std::chrono::steady_clock::now();
-    int attempts = 0;
-    double total = 0;
-    for (const LaneStrip &s : strips) total += lane_piece_cost(*s.fv.meta_host, s.T, 0, s.fv.tiles);
-    // How many wave slots: small calls are cut fine (chunk_cost, ~2 tiles of output rows: a piece's prologue is half of
-    // that, but such a launch is over in 10-20 us and only parallelism shortens it); once that would exceed the 4096
-    // waves the chip holds at this kernel's occupancy (256 CUs x 4 SIMDs x 4) the launch is WHOLE rounds of 4096 slots
-    // of ~55 K cycles each -- a partial last round is a tail with three quarters of the chip idle (C3 placements canvas:
-    // 38.9 us at 4096 slots, 43-46 at 3 700, 5 500 or 8 800), and within a round neighbouring chunks (which share
-    // source columns and taps through the XCD's L2) run together.  profiles/r05_lane_kernel.txt.
-    constexpr int kRound = 4096;
-    double n = total / chunk_cost;
-    if (n > kRound) n = kRound * std::max(1.0, std::floor(total / (kRound * 55000.0) + 0.5));
-    int n_slots = (int)std::min<double>(max_slots, std::max(32.0, n));
-    n_slots = std::max(32, n_slots / 32 * 32);
-    // every cut re-does up to three bands at the top of the next piece: ~ half a prologue + 2 bands per slot
-    // (+ 3 %: what the greedy cut loses at chunk ends; with it the first pass nearly always fits -- a pass is ~100 us of host time)
-    double target = 1.03 * (total + n_slots * (kLaneC0 + 2 * (kLaneCL + 2 * kLaneCH))) / n_slots;
-    std::vector<uint32_t> first;
-    pt->lane.reserve((size_t)n_slots + n_slots / 4 + strips.size());
-    for (int attempt = 0; attempt < 40; ++attempt, target *= 1.03) {
-        ++attempts;
-        pt->lane.clear();
-        first.assign(1, 0u);
-        double acc = 0;
-        const double tgt = target;
-        for (const LaneStrip &s : strips) {
-            const ResizePlan &p = plans[s.plan];
-            const std::vector<int32_t> &vm = *s.fv.meta_host;
-            const int ty = s.fv.tiles;
-            int y0 = 0;
-            while (y0 < ty) {
-                // the longest piece that still fits the chunk: cost grows with y1, nearly linearly -- start from the
-                // tile count the strip's average cost per tile row predicts and walk (a step or two) to the exact answer
-                int lo = y0;  // [y0, lo) fits (lo == y0: nothing yet)
-                if (acc + lane_piece_cost(vm, s.T, y0, ty) <= tgt) {
-                    lo = ty;
-                } else {
-                    const double per_tile = (kLaneCS + kLaneCV * s.T) + (kLaneCL + kLaneCH * s.T) * ((p.sh + 15) / 16) / (double)ty;
-                    const double room = tgt - acc - kLaneC0 - 2 * (kLaneCL + kLaneCH * s.T);
-                    lo = std::min(ty - 1, std::max(y0, y0 + (int)(room / per_tile)));
-                    while (lo > y0 && acc + lane_piece_cost(vm, s.T, y0, lo) > tgt) --lo;
-                    while (lo < ty - 1 && acc + lane_piece_cost(vm, s.T, y0, lo + 1) <= tgt) ++lo;
-                }
-                int y1 = lo;
-                if (y1 - y0 < std::min(2, ty - y0)) {
-                    if (acc > 0) {  // does not fit: close the chunk
-                        first.push_back((uint32_t)pt->lane.size());
-                        acc = 0;
-                        continue;
-                    }
-                    y1 = std::min(ty, y0 + 2);  // (an empty chunk takes at least two tiles)
-                }
-                RsLaneUnit u{};
-                u.T = s.T; u.n_vtiles = y1 - y0;
-                u.band0 = vm[4 * y0] >> 4;
-                u.band_last = vm[4 * (y1 - 1) + 1] & 0xFFFFFF;
-                u.plane_bytes = (uint32_t)((size_t)((p.sh + 15) / 16) * p.tiled_ct * 256);
-                u.band_bytes = (uint32_t)(p.tiled_ct * 256);
-                u.src = p.tiled_src + ((uint64_t)u.band0 * p.tiled_ct + s.ws / 16) * 256;
-                u.dst = s.dst;
-                u.hfrag = s.fh.frags + (uint64_t)s.t0 * 3072;
-                u.hbias = s.fh.bias + (uint64_t)s.t0 * 64;
-                u.vfrag = s.fv.frags + (uint64_t)y0 * 3072;
-                u.vbias = s.fv.bias + (uint64_t)y0 * 64;
-                u.vemit = s.fv.meta + ((uint64_t)4 * y0 + 1) * 4;
-                u.x0 = 16 * s.t0; u.row0 = 16 * y0; u.dw = p.dw; u.dh = p.dh;
-                acc += lane_piece_cost(vm, s.T, y0, y1);
-                pt->lane.push_back(u);
-                y0 = y1;
-                if (acc >= 0.97 * tgt) {
-                    first.push_back((uint32_t)pt->lane.size());
-                    acc = 0;
-                }
-            }
-        }
-        if (first.back() != pt->lane.size()) first.push_back((uint32_t)pt->lane.size());
-        if ((int)first.size() - 1 <= n_slots) break;
-    }
-    const int chunks = (int)first.size() - 1;
-    const int slots = std::max(32, (chunks + 31) / 32 * 32);  // whole workgroups, eight at a time
-    first.resize((size_t)slots + 1, (uint32_t)pt->lane.size());
-    pt->lane_slots = slots;
-    // records [0, slots): the slots' first pieces (a wave finds its work with ONE scalar load); further pieces of a
-    // chunk follow behind, chained through `next`
-    std::vector<RsLaneUnit> dealt((size_t)slots);
-    dealt.reserve((size_t)slots + pt->lane.size() - (size_t)chunks + 8);
-    const int n_wg = slots / 4, per = n_wg / 8;
-    static const bool in_order = [] { const char *e = getenv("MIC_RS_LANE_XCDMAP"); return e && atoi(e) == 0; }();  // (A/B: chunk c -> slot c)
-    for (int c = 0; c < slots; ++c) {
-        const int k = c / (4 * per), j = c % (4 * per);
-        const size_t slot = in_order ? (size_t)c : (size_t)(4 * (8 * (j / 4) + k) + (j % 4));
-        const uint32_t b0 = first[(size_t)c], b1 = first[(size_t)c + 1];
-        if (b0 == b1) continue;  // (an empty slot: the zero record, n_vtiles == 0)
-        dealt[slot] = pt->lane[b0];
-        size_t prev = slot;
-        for (uint32_t r = b0 + 1; r < b1; ++r) {
-            dealt[prev].next = (uint32_t)dealt.size();
-            prev = dealt.size();
-            dealt.push_back(pt->lane[r]);
-        }
-    }
-    pt->lane.swap(dealt);
-    if (trace)
-        fprintf(stderr, "lane_partition: %zu strips, model cost %.0f, %d slots asked, %d chunks, %zu records, %d pass(es), %.0f us\n",
-                strips.size(), total, n_slots, chunks, pt->lane.size(), attempts,
-                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
-}
-
 // Work units the marching kernel would cut a layer into (strips of 4 x-tiles x segments of seg tiles)
 int march_units(const ResizePlan &p, int64_t unit_px, int *seg_tiles_out) {
     const int tiles_x = (p.dw + 15) / 16, tiles_y = (p.dh + 15) / 16;
@@ -1118,20 +977,27 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
         if (p.march) march_px += (int64_t)p.dw * p.dh;
     const int64_t unit_px = march_unit_px(march_px);
     std::vector<LaneStrip> strips;
+    std::vector<std::shared_ptr<std::vector<int32_t>>> lane_meta;
     for (size_t pi = 0; pi < plans.size(); ++pi) {
         const ResizePlan &p = plans[pi];
         if (p.cached) continue;  // the pixels are in the resident layer cache: no pass
         const bool need_h = p.dw != p.sw, need_v = p.dh != p.sh;
         const uint64_t dst = p.dst_ptr ? p.dst_ptr : arena + p.dst_off;
         if (p.lane) {
+            FragEntry fh, fv;
+            if (int rc = get_frags(ctx, p.sw, p.dw, filter, stream, &fh, kFragsLaneH)) return rc;
+            if (int rc = get_frags(ctx, p.sh, p.dh, filter, stream, &fv, kFragsLaneV)) return rc;
+            pt->frag_refs.push_back(fh.buf);
+            pt->frag_refs.push_back(fv.buf);
+            lane_meta.push_back(fv.meta_host);  // (the strips point into it until the cut below)
             LaneStrip st{};
-            if (int rc = get_frags(ctx, p.sw, p.dw, filter, stream, &st.fh, kFragsLaneH)) return rc;
-            if (int rc = get_frags(ctx, p.sh, p.dh, filter, stream, &st.fv, kFragsLaneV)) return rc;
-            pt->frag_refs.push_back(st.fh.buf);
-            pt->frag_refs.push_back(st.fv.buf);
-            st.plan = pi; st.dst = dst;
-            const std::vector<int32_t> &hm = *st.fh.meta_host;
-            for (int t = 0; t < st.fh.tiles; ++t) {
+            st.sh = p.sh; st.dw = p.dw; st.dh = p.dh;
+            st.tiled_ct = p.tiled_ct; st.tiled_src = p.tiled_src; st.dst = dst;
+            st.hfrag = fh.frags; st.hbias = fh.bias;
+            st.vfrag = fv.frags; st.vbias = fv.bias; st.vmeta = fv.meta;
+            st.vm = fv.meta_host->data(); st.ty = fv.tiles;
+            const std::vector<int32_t> &hm = *fh.meta_host;
+            for (int t = 0; t < fh.tiles; ++t) {
                 if (hm[4 * t + 1] == 0) continue;  // (the second tile of a group)
                 st.t0 = t; st.T = hm[4 * t + 1]; st.ws = hm[4 * t];
                 strips.push_back(st);
@@ -1219,7 +1085,12 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             pt->max_v_out_h = std::max(pt->max_v_out_h, p.dh);
         }
     }
-    if (!strips.empty()) lane_partition(plans, strips, ctx->lane_chunk, ctx->lane_max_slots, pt);
+    if (!strips.empty()) {
+        LaneCut cut;
+        lane_partition(strips, ctx->lane_chunk, ctx->lane_max_slots, &cut);
+        pt->lane.swap(cut.records);
+        pt->lane_slots = cut.slots;
+    }
     // tile kernel: whole-window entries first, banded ones after (two instantiations, launch_resample_tile)
     auto whole = [](const RsTile &f) { return f.rows16 >= f.pitch_r; };
     pt->tiles_whole = (int)(std::stable_partition(pt->tiles.begin(), pt->tiles.end(), whole) - pt->tiles.begin());

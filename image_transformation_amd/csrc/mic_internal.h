@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "lane_unit.h"
+
 namespace mic {
 
 // Device addresses travel as integers inside the job tables; casting them to address space 1
@@ -171,28 +173,6 @@ static_assert(sizeof(PlanarJob) == 32, "PlanarJob layout");
 hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream);
 hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_resample_tile(const RsTile *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes, hipStream_t stream);
-// One WAVE's work in the lane kernel (kernels_resample_lane.hip): T adjacent tiles of 16 output columns whose taps fit
-// one 64-column window of the cutout's TILED planar copy, marched from band band0 to band_last, emitting n_vtiles tiles
-// of 16 output rows.  Everything a wave needs first is in the record: scalar loads, then one round of vector loads.
-// Record s (s < slots) is the first piece of wave slot s (n_vtiles == 0: the slot has nothing to do); the few slots
-// whose equal-cost chunk falls across the end of a strip chain further pieces through `next` (records >= slots).
-struct alignas(16) RsLaneUnit {
-    uint64_t src;        // plane 0 of the tiled planar copy, at tile (band0, first window tile)
-    uint64_t dst;        // the layer's pixels (row-major RGBA, dw x dh)
-    uint64_t hfrag;      // [T][3][64][16]: horizontal tap digits of the unit's x-tiles against ITS window
-    uint64_t hbias;      // [T][16] int32
-    uint64_t vfrag;      // [n_vtiles][3][64][16]: vertical tap digits in ring order (band b at k bytes 4 (b & 3) .. + 3)
-    uint64_t vbias;      // [n_vtiles][16] int32
-    uint64_t vemit;      // [n_vtiles] int32: band after which the tile can be emitted | ring words it reads << 24
-    uint32_t plane_bytes, band_bytes;  // bytes between planes / between bands of tiles
-    int32_t band0, band_last;
-    int32_t n_vtiles, T;
-    int32_t x0, row0;    // first output column / row of the unit
-    int32_t dw, dh;
-    uint32_t next;       // index of the wave's next piece (0: none) -- records [0, slots) are the slots' FIRST pieces
-    int32_t pad[7];
-};
-static_assert(sizeof(RsLaneUnit) == 128, "RsLaneUnit layout");
 #ifndef MIC_RS_LANE_WAVES
 #define MIC_RS_LANE_WAVES 4  // waves per SIMD the lane kernel's register budget is set for
 #endif

@@ -163,3 +163,21 @@ def test_host_pool_under_tsan(tmp_path):
     assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
     assert b"ThreadSanitizer" not in r.stderr and b"data race" not in r.stderr, r.stderr[-3000:]
     assert b"bad=0" in r.stdout and b"loops=1200" in r.stdout and b"fork_child=ok" in r.stdout, r.stdout
+
+
+def test_lane_partition_under_asan_ubsan(tmp_path):
+    """csrc/lane_partition.h (the host-side cut of a lane-kernel launch into equal-cost chunks, dealt XCD by XCD; round 5) on 60
+    random launches through the real lane-form axis tables: every tile of output rows of every strip emitted exactly once,
+    every record reachable from exactly one wave slot, bands / table addresses / window bounds as the tables say."""
+    if shutil.which("g++") is None:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "lane_partition_san")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", CSRC,
+           os.path.join(ROOT, "tests", "native", "lane_partition_main.cpp"), os.path.join(CSRC, "resample_coeffs.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "asan" in (r.stderr or "").lower() and "cannot find" in r.stderr.lower():
+        pytest.skip("libasan not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-3000:])
+    assert b"launches=60" in r.stdout and b" ok" in r.stdout, r.stdout
