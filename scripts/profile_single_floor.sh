@@ -1,14 +1,14 @@
 #!/bin/bash
 # Kernel durations (rocprofv3 --kernel-trace) of single-canvas composite launches against the page-writer floor
-# (scripts/ubench_page.bin) and, when scripts/var_cabl1.bin / var_cabl2.bin exist, the stage-skipping builds.
+# (build/ubench_page.bin) and, when build/var_cabl1.bin / var_cabl2.bin (scripts/build_variant.sh with the sed edits of profiles/r05_single_canvas_floor.txt) exist, the stage-skipping builds.
 set -u
 cd "${GRAFT_REPO_ROOT:?run through gpurun: GRAFT_REPO_ROOT names the copy of the repo on the GPU box}" || exit 1
 export TMPDIR=/tmp
 out=gpurun_out/prof_single_floor
 rm -rf $out && mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out/floor -- scripts/ubench_page.bin > $out/floor.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out/floor -- build/ubench_page.bin > $out/floor.log 2>&1
 for v in full cabl1 cabl2; do
-  if [ $v = full ]; then unset MIC_LIB; elif [ -f scripts/var_$v.bin ]; then export MIC_LIB=$PWD/scripts/var_$v.bin; else continue; fi
+  if [ $v = full ]; then unset MIC_LIB; elif [ -f build/var_$v.bin ]; then export MIC_LIB=$PWD/build/var_$v.bin; else continue; fi
   rocprofv3 --kernel-trace --output-format csv -d $out/$v -- python3 scripts/prof_single.py > $out/$v.log 2>&1
 done
 unset MIC_LIB
