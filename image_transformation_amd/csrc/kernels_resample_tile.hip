@@ -237,10 +237,36 @@ __device__ __forceinline__ void store_pixels(const uint32_t (&w)[4], gptr dst, i
         if (ox < dw && oy + r < dh) dst[(uint32_t)((oy + r) * dw + ox)] = unpremultiply_with(px[r], recip);  // < 2^31 px
 }
 
+// What a wave needs of one axis' tables for the tile it keeps: the tile's table entry, the accumulators' initial
+// values, where its fragments start and the first chunk's three digit fragments.
+struct AxisOperands {
+    v4i m, bias;
+    gv4ptr fbase;
+    v4i f[3];
+};
+// horizontal: the bias is per output column (the C/D column of a lane)
+__device__ __forceinline__ AxisOperands h_operands(const RsTile &J, int xt, int lane) {
+    AxisOperands o;
+    o.m = reinterpret_cast<gv4ptr>(J.hmeta)[xt];
+    const int b = reinterpret_cast<gciptr>(J.hbias)[xt * 16 + (lane & 15)];
+    o.bias = v4i{b, b, b, b};
+    o.fbase = reinterpret_cast<gv4ptr>(J.hfrag) + (size_t)o.m[2] * 3 * 64 + lane;
+    o.f[0] = o.fbase[0]; o.f[1] = o.fbase[64]; o.f[2] = o.fbase[128];
+    return o;
+}
+// vertical: per output row (the lane's four C/D rows)
+__device__ __forceinline__ AxisOperands v_operands(const RsTile &J, int yt, int lane) {
+    AxisOperands o;
+    o.m = reinterpret_cast<gv4ptr>(J.vmeta)[yt];
+    o.bias = *reinterpret_cast<gv4ptr>(reinterpret_cast<gciptr>(J.vbias) + yt * 16 + 4 * (lane >> 4));
+    o.fbase = reinterpret_cast<gv4ptr>(J.vfrag) + (size_t)o.m[2] * 3 * 64 + lane;
+    o.f[0] = o.fbase[0]; o.f[1] = o.fbase[64]; o.f[2] = o.fbase[128];
+    return o;
+}
+
 template <bool BANDED>
-__global__ __launch_bounds__(256) void resample_tile_kernel(const RsTile *__restrict__ jobs) {
+__device__ __forceinline__ void resample_tile(const RsTile &J) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds8[];
-    const RsTile J = jobs[blockIdx.y];
     // XCD-aware tile order (see RsTile): blockIdx.x & 7 is the XCD this workgroup lands on
     const int tile = (((int)blockIdx.x + J.xcd_rot) & 7) * (4 * J.n_entries) + 4 * J.entry + ((int)blockIdx.x >> 3);
     if (tile >= J.tiles_x * J.tiles_y) return;
@@ -303,15 +329,18 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(const RsTile *__rest
         // ---- 2. horizontal pass: window rows -> 8-bit intermediate, transposed.  A wave keeps one
         // x-tile (its tap fragments stay in registers) and walks the row tiles two at a time: the second
         // tile's MFMAs run in the matrix pipe while the VALU does the first tile's epilogue.
+        // (Requesting this tile's and the vertical pass' tap fragments up front, together with the window, instead of
+        // behind the barriers was built and measured in round 5: 24 more registers, and the small calls it was meant
+        // for did not move -- 8.28 us against 8.28 for the reference-sized call, 7.40 against 7.44 for thumbnails.
+        // profiles/r05_small_calls.txt, r05_tile_eager.patch.)
         const int groups = 4 / n_xt;  // waves per x-tile (n_xt <= 4)
         if (wave < n_xt * groups) {
             const int xi = wave % n_xt, sub = wave / n_xt;
             const int n_rt = (Rb + 15) >> 4;
-            const v4i m = hmeta[xt0 + xi];
-            const int b = reinterpret_cast<gciptr>(J.hbias)[(xt0 + xi) * 16 + l15];
-            const v4i bias = {b, b, b, b};
-            gv4ptr fbase = reinterpret_cast<gv4ptr>(J.hfrag) + (size_t)m[2] * 3 * 64 + lane;
-            const v4i f[3] = {fbase[0], fbase[64], fbase[128]};
+            const AxisOperands H = h_operands(J, xt0 + xi, lane);
+            const v4i m = H.m, bias = H.bias;
+            gv4ptr fbase = H.fbase;
+            const v4i f[3] = {H.f[0], H.f[1], H.f[2]};
             const uint8_t *a0 = srcP + l15 * J.pitch_c + (m[0] - c_lo) + 16 * lh;      // + 16 rt pitch_c
             uint8_t *m0 = midT + (xi * 16 + l15) * J.pitch_r + band0 + 4 * lh;         // + 16 rt
             for (int rt = sub; rt < n_rt; rt += 2 * groups) {
@@ -342,10 +371,10 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(const RsTile *__rest
         const int groups = 4 / n_yt;
         if (wave < n_yt * groups) {
             const int yi = wave % n_yt, sub = wave / n_yt;
-            const v4i m = vmeta[yt0 + yi];
-            const v4i bias = *reinterpret_cast<gv4ptr>(reinterpret_cast<gciptr>(J.vbias) + (yt0 + yi) * 16 + 4 * lh);
-            gv4ptr fbase = reinterpret_cast<gv4ptr>(J.vfrag) + (size_t)m[2] * 3 * 64 + lane;
-            const v4i f[3] = {fbase[0], fbase[64], fbase[128]};
+            const AxisOperands V = v_operands(J, yt0 + yi, lane);
+            const v4i m = V.m, bias = V.bias;
+            gv4ptr fbase = V.fbase;
+            const v4i f[3] = {V.f[0], V.f[1], V.f[2]};
             const uint8_t *b0 = midT + l15 * J.pitch_r + (m[0] - r_lo) + 16 * lh;      // + 16 xi pitch_r
             gptr dst = reinterpret_cast<gptr>(J.dst);
             const int oy0 = (yt0 + yi) * 16 + 4 * lh;
@@ -368,11 +397,26 @@ __global__ __launch_bounds__(256) void resample_tile_kernel(const RsTile *__rest
     }
 }
 
+template <bool BANDED>
+__global__ __launch_bounds__(256) void resample_tile_kernel(const RsTile *__restrict__ jobs) {
+    const RsTile J = jobs[blockIdx.y];
+    resample_tile<BANDED>(J);
+}
+// A handful of whole-window entries, handed over BY VALUE in the kernel arguments (like the composite kernel's single
+// job): the reference's own call -- three or four cutouts resized onto one small canvas, compositor.py:18-21 -- then
+// stages and uploads nothing at all, and a workgroup's entry comes through scalar loads from the argument segment.
+__global__ __launch_bounds__(256) void resample_tile_args_kernel(const RsTileArgs args) {
+    const RsTile J = args.t[blockIdx.y];
+    resample_tile<false>(J);
+}
+
 }  // namespace
 
 // jobs_dev[0, n_whole) keep their whole source window in LDS, jobs_dev[n_whole, n_jobs) are banded.
+// jobs_host: the same entries on the host; when they all fit the argument block (rs_tile_in_args) the launch carries them
+// and jobs_dev is not read.
 hipError_t launch_resample_tile(const RsTile *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes,
-                                hipStream_t stream) {
+                                hipStream_t stream, const RsTile *jobs_host) {
     if (n_jobs <= 0) return hipSuccess;
     // opt the kernels in for more than 64 KB of dynamic LDS, once per device of this process
     static std::atomic<bool> attr_set[64];
@@ -380,13 +424,21 @@ hipError_t launch_resample_tile(const RsTile *jobs_dev, int n_jobs, int n_whole,
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_tile_kernel<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsTileMaxLds);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(resample_tile_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsTileMaxLds);
-        if (e != hipSuccess) return e;
+        const void *forms[3] = {reinterpret_cast<const void *>(resample_tile_kernel<false>),
+                                reinterpret_cast<const void *>(resample_tile_kernel<true>),
+                                reinterpret_cast<const void *>(resample_tile_args_kernel)};
+        for (const void *f : forms) {
+            e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRsTileMaxLds);
+            if (e != hipSuccess) return e;
+        }
         if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
+    }
+    if (jobs_host && rs_tile_in_args(n_jobs, n_whole)) {
+        RsTileArgs args{};
+        std::copy(jobs_host, jobs_host + n_jobs, args.t);
+        hipLaunchKernelGGL(resample_tile_args_kernel, dim3((unsigned)kRsTilesPerEntry, (unsigned)n_jobs), dim3(256), lds_bytes,
+                           stream, args);
+        return hipGetLastError();
     }
     for (int first = 0; first < n_whole; first += 65535) {  // grid.y limit
         const int n = std::min(65535, n_whole - first);

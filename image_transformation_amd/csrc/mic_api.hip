@@ -223,6 +223,7 @@ struct mic_ctx {
     uint32_t *median_scratch = nullptr;  // device: two sets of histogram slots (a double buffer) + kMedianMaxBatch result words
     MedianState median_state;            // which half the next call works in, what the previous one left to clear
     bool layer_args = true;              // MIC_LAYER_ARGS=0: single-canvas launches read their layer records from the device table
+    bool tile_args = true;               // MIC_RS_TILE_ARGS=0: the tile kernel always reads its entries from the device table
     int median_two_launches = -1;        // MIC_MEDIAN_TWO_LAUNCHES=1 / 0: force the two-launch / one-launch median (-1: by image size)
     uint32_t *gradient_table = nullptr;  // device: fill_gradient's per-position colours (allocated on first use)
     uint32_t *median_host = nullptr;     // pinned
@@ -339,6 +340,7 @@ extern "C" int mic_create(int device, mic_ctx **out) {
     }
     tick("8 events");
     if (const char *la = getenv("MIC_LAYER_ARGS")) ctx->layer_args = atoi(la) != 0;
+    if (const char *ta = getenv("MIC_RS_TILE_ARGS")) ctx->tile_args = atoi(ta) != 0;
     if (const char *v = getenv("MIC_LAYER_CACHE_MB")) ctx->layer_cache_cap = (size_t)std::max(0ll, atoll(v)) << 20;
     if (const char *tl = getenv("MIC_MEDIAN_TWO_LAUNCHES")) ctx->median_two_launches = atoi(tl) != 0 ? 1 : 0;
     e = hipMalloc(&ctx->median_scratch, (kMedianScratchWords + 64) * sizeof(uint32_t));
@@ -1657,6 +1659,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
     int class_end[3] = {0, 0, 0};
     int pitch = 0;
     char *dp = nullptr;
+    bool tiles_in_args = false;
     if (cached) {
         memcpy(class_end, slot_tab->class_end, sizeof class_end);
         pitch = slot_tab->pitch;
@@ -1717,9 +1720,12 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
         Slot *slot = nullptr;
         if (P->persistent && one) {
             dp = static_cast<char *>(P->tables_dev);
-        } else if (pack_layers && P->pt.fused.empty() && P->pt.tiles.empty() && P->pt.h.empty() && P->pt.v.empty() && P->pt.lane.empty()) {
-            // one canvas, <= 64 identity-scale layers (the reference's own call, compositor.py:6-22 from the Flex
-            // pipeline): job AND layer records ride in the kernel arguments -- nothing is staged, nothing uploaded
+        } else if (pack_layers && P->pt.fused.empty() && P->pt.h.empty() && P->pt.v.empty() && P->pt.lane.empty() &&
+                   (P->pt.tiles.empty() || (ctx->tile_args && rs_tile_in_args((int)P->pt.tiles.size(), P->pt.tiles_whole)))) {
+            // one canvas, <= 64 layers, identity-scale (the reference's own call from the Flex pipeline,
+            // compositor.py:6-22) or a handful resized by the tile kernel (its own LANCZOS call, compositor.py:18-21):
+            // job, layer records AND tile entries ride in the kernel arguments -- nothing is staged, nothing uploaded
+            tiles_in_args = !P->pt.tiles.empty();
             static char nothing[64];
             dp = nothing;  // (no table is read through it: every launcher below sees a count of 0)
         } else {
@@ -1776,7 +1782,7 @@ static int plan_submit(mic_plan *P, void *const *outs, hipStream_t stream) {
             HIP_TRY(launch_resample_lane(reinterpret_cast<const RsLaneUnit *>(dp + P->off_lane), P->pt.lane_slots, stream));
         HIP_TRY(launch_resample_march(fused_dev, (int)P->pt.fused.size(), P->pt.lds_march, stream));
         HIP_TRY(launch_resample_tile(reinterpret_cast<const RsTile *>(dp + P->off_t), (int)P->pt.tiles.size(),
-                                      P->pt.tiles_whole, P->pt.tiles_lds, stream));
+                                      P->pt.tiles_whole, P->pt.tiles_lds, stream, tiles_in_args ? P->pt.tiles.data() : nullptr));
         HIP_TRY(launch_resample_h(reinterpret_cast<const RsJob *>(dp + P->off_h), (int)P->pt.h.size(),
                                   P->pt.max_h_out_w, P->pt.max_h_rows, stream));
         HIP_TRY(launch_resample_v(reinterpret_cast<const RsJob *>(dp + P->off_v), (int)P->pt.v.size(),
@@ -2102,6 +2108,11 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
     PassTables pt;
     std::vector<ResizePlan> plans{rp};
     if (int rc = plan_passes(ctx, plans, filter, ctx->arena, stream, &pt)) return rc;
+    if (ctx->tile_args && pt.h.empty() && pt.v.empty() && rs_tile_in_args((int)pt.tiles.size(), pt.tiles_whole)) {
+        // (a small image: its tile entries ride in the kernel arguments, nothing is staged or uploaded)
+        HIP_TRY(launch_resample_tile(nullptr, (int)pt.tiles.size(), pt.tiles_whole, pt.tiles_lds, stream, pt.tiles.data()));
+        return MIC_OK;
+    }
     const size_t off_v = 64, off_t = 128;
     const size_t total = off_t + sizeof(RsTile) * std::max<size_t>(1, pt.tiles.size());
     Slot *slot = nullptr;

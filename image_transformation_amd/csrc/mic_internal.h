@@ -143,6 +143,12 @@ inline size_t rs_tile_lds_bytes(int rows16, int pitch_c, int tx16, int pitch_r) 
 }
 constexpr size_t kRsTilePreferredLds = 52 * 1024;  // three workgroups per CU (160 KB of LDS, 1 KB static each)
 constexpr size_t kRsTileMaxLds = 150 * 1024;       // last resort before the two-pass fallback
+// Up to this many whole-window entries ride in the kernel arguments (2 KiB of the 4 KiB segment)
+constexpr int kRsTileArgJobs = 16;
+struct RsTileArgs {
+    RsTile t[kRsTileArgJobs];
+};
+inline bool rs_tile_in_args(int n_jobs, int n_whole) { return n_jobs > 0 && n_jobs == n_whole && n_jobs <= kRsTileArgJobs; }
 // The launch is a (tiles per entry) x (entries) grid: a layer with more tiles takes several entries,
 // so that small layers do not pad the grid out to the largest layer's tile count.
 constexpr int kRsTilesPerEntry = 32;
@@ -172,7 +178,8 @@ struct alignas(16) PlanarJob {
 static_assert(sizeof(PlanarJob) == 32, "PlanarJob layout");
 hipError_t launch_planarize(const PlanarJob *jobs_dev, int n_jobs, int64_t max_items, hipStream_t stream);
 hipError_t launch_resample_march(const RsMarch *jobs_dev, int n_jobs, size_t lds_bytes, hipStream_t stream);
-hipError_t launch_resample_tile(const RsTile *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_resample_tile(const RsTile *jobs_dev, int n_jobs, int n_whole, size_t lds_bytes, hipStream_t stream,
+                                const RsTile *jobs_host = nullptr);
 #ifndef MIC_RS_LANE_WAVES
 #define MIC_RS_LANE_WAVES 4  // waves per SIMD the lane kernel's register budget is set for
 #endif

@@ -15,7 +15,7 @@ import cases  # noqa: E402
 import oracle  # noqa: E402
 
 P = ctypes.c_void_p
-KNOBS = ("MIC_RS_MARCH_MIN_UNITS", "MIC_LAYER_CACHE_MB", "MIC_RS_LANE", "MIC_RS_LANE_MIN_SLOTS")
+KNOBS = ("MIC_RS_MARCH_MIN_UNITS", "MIC_LAYER_CACHE_MB", "MIC_RS_LANE", "MIC_RS_LANE_MIN_SLOTS", "MIC_RS_TILE_ARGS")
 # which resample kernel a context routes qualifying layers to (mic_api.hip: routing)
 ROUTES = {"tile": {"MIC_RS_LANE": 0}, "march": {"MIC_RS_LANE": 0, "MIC_RS_MARCH_MIN_UNITS": 0}, "lane": {"MIC_RS_LANE_MIN_SLOTS": 0}}
 
@@ -188,3 +188,53 @@ def test_layer_cache_too_small_or_full(monkeypatch):
             assert sum(hits) > 0 and all(h == 0 for k, h in enumerate(hits) if k % 10 == 9)
         del atlas
         assert lib.mic_destroy(ctx.handle) == 0
+
+
+@pytest.mark.parametrize("in_args", [1, 0])
+def test_tile_entries_in_kernel_arguments_boundary(in_args, monkeypatch):
+    """A single canvas with at most 16 distinct resized layers (the reference's own call: compositor.py:18-21, three or four
+    cutouts) hands the tile kernel its entries in the kernel arguments (kRsTileArgJobs, mic_internal.h) and uploads nothing;
+    beyond that, with MIC_RS_TILE_ARGS=0, or when a layer is a deep shrink (banded entry) they come from the device table.
+    1, 15, 16, 17 and 40 resized layers, mic_composite_batch with the layer cache cleared and mic_resize of a small image:
+    equal to the oracle either way."""
+    import torch
+    from image_transformation_amd import _native
+    from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
+    ctx = _ctx(monkeypatch, MIC_RS_LANE=0, MIC_RS_TILE_ARGS=in_args)
+    lib = _native.lib()
+    syn = cases.synthetic
+    rng = np.random.default_rng(1600 + in_args)
+    objs = syn.make_cutouts(7, (30, 120), (24, 100), seed=161, alpha_mode="soft")
+    objs[8] = syn.make_cutout(rng, 64, 1500, "soft")  # 1500 rows -> 20: a banded entry
+    atlas = Atlas(objs, ctx=ctx)
+    W, H = 492, 492
+    bg = np.empty((H, W, 4), np.uint8)
+    bg[:] = (220, 238, 245, 255)
+    cv = SolidCanvas((W, H), (220, 238, 245, 255))
+    for n, deep in ((1, False), (15, False), (16, False), (17, False), (40, False), (4, True)):
+        pl = []
+        for k in range(n):
+            oid = 1 + k % 7
+            sh, sw = objs[oid].shape[:2]
+            bw, bh = max(1, int(sw * (0.55 + 0.045 * k))), max(1, int(sh * (1.9 - 0.03 * k)))  # every layer its own size
+            x1, y1 = int(rng.integers(-bw // 3, W - bw // 2)), int(rng.integers(-bh // 3, H - bh // 2))
+            pl.append({"object_id": oid, "box": [x1, y1, x1 + bw, y1 + bh]})
+        if deep:
+            pl.append({"object_id": 8, "box": [100, 200, 100 + 60, 200 + 20]})
+        want = oracle.composite(bg, objs, pl)
+        for rep in range(2):
+            assert lib.mic_layer_cache_clear(ctx.handle) == 0
+            got = composite_device(atlas, [cv], [coerce_placements(atlas, pl)])[0].cpu().numpy()
+            assert np.array_equal(got, want), (n, deep, rep)
+            st = ctx.stats()
+            assert st["resampled_layers"] == len(pl) and st["marched_layers"] == 0 and st["cached_layers"] == 0, st
+    # mic_resize of a small image: one entry, in the arguments
+    src = syn.make_cutout(rng, 90, 70, "soft")
+    dev = torch.from_numpy(src).cuda()
+    for dw, dh in ((108, 84), (45, 100), (300, 17)):
+        dst = torch.empty((dh, dw, 4), dtype=torch.uint8, device="cuda")
+        _native.check(lib.mic_resize(ctx.handle, P(dev.data_ptr()), 90, 70, P(dst.data_ptr()), dw, dh, 0, P(ctx.stream_ptr())))
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), oracle.resize(src, (dw, dh))), (dw, dh)
+    del atlas
+    assert lib.mic_destroy(ctx.handle) == 0
