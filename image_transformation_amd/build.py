@@ -137,7 +137,8 @@ def check_isa(verbose: bool = False) -> None:
     if not m:
         raise RuntimeError("check_isa: resample_lane_kernel not found in the assembly")
     lane = m.group(2)
-    if lane.count("v_ashr_pk_u8_i32") < 16 or lane.count("v_ashr_pk_i8_i32") < 16 or lane.count("v_mfma_i32_16x16x64_i8") < 96:
+    # (six bodies: one or two x-tiles x general / keeps width / keeps height: 288 + 192 + 192 MFMAs)
+    if lane.count("v_ashr_pk_u8_i32") < 48 or lane.count("v_ashr_pk_i8_i32") < 48 or lane.count("v_mfma_i32_16x16x64_i8") < 600:
         raise RuntimeError("check_isa: the lane kernel lost its MFMA chains / v_ashr_pk_{u8,i8}_i32 epilogues")
     if "scratch_" in lane:
         raise RuntimeError("check_isa: the lane kernel spills to scratch (its band loop then waits on scratch traffic: 62 us measured)")

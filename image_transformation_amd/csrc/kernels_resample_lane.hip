@@ -50,8 +50,11 @@ __device__ __forceinline__ V pinned(V v) {
 
 // One piece: march bands band0 .. band_last of the window columns, emit the piece's tiles of output rows.
 // hf_lds: this WAVE's own LDS region for the horizontal tap fragments of the piece's x-tiles.
-template <int T>
+// HD / VD: tap digits of the horizontal / vertical pass -- 3, or 1 for an axis that keeps its size (tile4: the last digit
+// alone, no floor shifts; that one MFMA per channel is also the transposition between the passes' operand layouts).
+template <int T, int HD, int VD>
 __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const float *recip, const int lane) {
+    static_assert((HD == 3 || HD == 1) && (VD == 3 || VD == 1) && HD + VD > 2, "identity forms");
     const int l15 = lane & 15, lh = lane >> 4;
     const uint32_t lane16 = (uint32_t)lane * 16u, l15x4 = (uint32_t)l15 * 4u;
     const int band0 = pinned(U.band0), band_last = pinned(U.band_last), n_vt = pinned(U.n_vtiles);
@@ -92,7 +95,8 @@ __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const
     auto fetch_taps = [&](int t) __attribute__((always_inline)) {
         vb = *at<int32_t>(vbias, (uint32_t)t * 64u + l15x4);
         gv4ptr base = at<v4i>(vfrag, (uint32_t)t * 3072u + lane16);
-        vf[0] = base[0]; vf[1] = base[64]; vf[2] = base[128];
+        if (VD == 3) { vf[0] = base[0]; vf[1] = base[64]; }
+        vf[2] = base[128];
     };
     fetch_taps(0);
     int yt = 0;
@@ -143,7 +147,7 @@ __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const
                 uint32_t w[4];
                 int hb = hbias1[j];
                 asm volatile("" : "+v"(hb));
-                tile4<true>([&](int c) { return a[c]; }, hf, v4i{hb, hb, hb, hb}, w);
+                tile4<true, HD>([&](int c) { return a[c]; }, hf, v4i{hb, hb, hb, hb}, w);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) ring[j][c][q] = (int)w[c];
             }
@@ -164,7 +168,7 @@ __device__ __forceinline__ void lane_run(const RsLaneUnit &U, v4i *hf_lds, const
                 px[j] = u32x4{0u, 0u, 0u, 0u};
                 if (!all_zero) {
                     uint32_t w[4];
-                    tile4<false>([&](int c) { return ring[j][c]; }, vf, v4i{vb, vb, vb, vb}, w);
+                    tile4<false, VD>([&](int c) { return ring[j][c]; }, vf, v4i{vb, vb, vb, vb}, w);
                     if (j == T - 1) fetch_taps(t_n);
                     // alpha bytes all 0 or 255 <=> low 7 bits of every byte equal its top bit
                     const uint32_t top = (w[3] >> 7) & 0x01010101u;
@@ -214,10 +218,23 @@ __global__ __launch_bounds__(256, MIC_RS_LANE_WAVES) void resample_lane_kernel(c
         const RsLaneUnit &U = units[r];
         r = U.next;
         if (U.n_vtiles > 0) {
-            if (U.T == 1)
-                lane_run<1>(U, hf_lds[wave], recip, lane);
-            else
-                lane_run<2>(U, hf_lds[wave], recip, lane);
+            // (wave-uniform; the forms for layers that keep one axis are code a launch without such layers never fetches)
+            if (U.cls == kLaneGeneral) {
+                if (U.T == 1)
+                    lane_run<1, 3, 3>(U, hf_lds[wave], recip, lane);
+                else
+                    lane_run<2, 3, 3>(U, hf_lds[wave], recip, lane);
+            } else if (U.cls == kLaneKeepsWidth) {
+                if (U.T == 1)
+                    lane_run<1, 1, 3>(U, hf_lds[wave], recip, lane);
+                else
+                    lane_run<2, 1, 3>(U, hf_lds[wave], recip, lane);
+            } else {
+                if (U.T == 1)
+                    lane_run<1, 3, 1>(U, hf_lds[wave], recip, lane);
+                else
+                    lane_run<2, 3, 1>(U, hf_lds[wave], recip, lane);
+            }
         }
     } while (r != 0u);
 }

@@ -36,6 +36,7 @@ struct LaneStrip {   // one column strip of a layer: T x-tiles from t0 (window s
     uint64_t vfrag, vbias, vmeta;  // the vertical axis' (kFragsLaneV): fragments, bias, meta rows (device)
     const int32_t *vm;           // ... and the meta rows on the host: [ty][4] = {first tap row, last band | ring words << 24, chunk, end}
     int ty;                      // tiles of 16 output rows
+    int cls;                     // kLaneGeneral / kLaneKeepsWidth / kLaneKeepsHeight (lane_unit.h)
 };
 
 struct LaneCut {
@@ -110,7 +111,7 @@ inline void lane_partition(const std::vector<LaneStrip> &strips, double chunk_co
                     y1 = std::min(ty, y0 + 2);  // (an empty chunk takes at least two tiles)
                 }
                 RsLaneUnit u{};
-                u.T = s.T; u.n_vtiles = y1 - y0;
+                u.T = s.T; u.n_vtiles = y1 - y0; u.cls = s.cls;
                 u.band0 = vm[4 * y0] >> 4;
                 u.band_last = vm[4 * (y1 - 1) + 1] & 0xFFFFFF;
                 u.plane_bytes = (uint32_t)((size_t)((s.sh + 15) / 16) * s.tiled_ct * 256);

@@ -24,7 +24,13 @@ struct alignas(16) RsLaneUnit {
     int32_t x0, row0;    // first output column / row of the unit
     int32_t dw, dh;
     uint32_t next;       // index of the wave's next piece (0: none) -- records [0, slots) are the slots' FIRST pieces
-    int32_t pad[7];
+    int32_t cls;         // kLaneGeneral, or the layer keeps its width / height (below)
+    int32_t pad[6];
 };
 static_assert(sizeof(RsLaneUnit) == 128, "RsLaneUnit layout");
+// Piece classes: a layer that keeps one axis (the pass Pillow skips, Resample.c need_horizontal / need_vertical; call site
+// compositor.py:20) runs that axis as ONE MFMA per channel and no floor shifts -- every tap is 2^22 or 0, so the two low
+// digits are zero and the chain collapses to its last link; what is left is the transposition between the two passes'
+// operand layouts.  A wave-uniform choice per piece inside one launch.
+enum : int32_t { kLaneGeneral = 0, kLaneKeepsWidth = 1, kLaneKeepsHeight = 2 };
 }  // namespace mic

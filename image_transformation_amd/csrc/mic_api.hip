@@ -224,6 +224,7 @@ struct mic_ctx {
     MedianState median_state;            // which half the next call works in, what the previous one left to clear
     bool layer_args = true;              // MIC_LAYER_ARGS=0: single-canvas launches read their layer records from the device table
     bool tile_args = true;               // MIC_RS_TILE_ARGS=0: the tile kernel always reads its entries from the device table
+    bool lane_keeps = true;              // MIC_RS_LANE_KEEPS=0: layers that keep one axis run the general lane kernel
     int median_two_launches = -1;        // MIC_MEDIAN_TWO_LAUNCHES=1 / 0: force the two-launch / one-launch median (-1: by image size)
     uint32_t *gradient_table = nullptr;  // device: fill_gradient's per-position colours (allocated on first use)
     uint32_t *median_host = nullptr;     // pinned
@@ -341,6 +342,7 @@ extern "C" int mic_create(int device, mic_ctx **out) {
     tick("8 events");
     if (const char *la = getenv("MIC_LAYER_ARGS")) ctx->layer_args = atoi(la) != 0;
     if (const char *ta = getenv("MIC_RS_TILE_ARGS")) ctx->tile_args = atoi(ta) != 0;
+    if (const char *lk = getenv("MIC_RS_LANE_KEEPS")) ctx->lane_keeps = atoi(lk) != 0;
     if (const char *v = getenv("MIC_LAYER_CACHE_MB")) ctx->layer_cache_cap = (size_t)std::max(0ll, atoll(v)) << 20;
     if (const char *tl = getenv("MIC_MEDIAN_TWO_LAUNCHES")) ctx->median_two_launches = atoi(tl) != 0 ? 1 : 0;
     e = hipMalloc(&ctx->median_scratch, (kMedianScratchWords + 64) * sizeof(uint32_t));
@@ -999,6 +1001,8 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
             st.vfrag = fv.frags; st.vbias = fv.bias; st.vmeta = fv.meta;
             st.vm = fv.meta_host->data(); st.ty = fv.tiles;
             const std::vector<int32_t> &hm = *fh.meta_host;
+            // a layer that keeps its width or its height: the pass Pillow skips (Resample.c need_horizontal / need_vertical)
+            st.cls = !ctx->lane_keeps ? kLaneGeneral : !need_h ? kLaneKeepsWidth : !need_v ? kLaneKeepsHeight : kLaneGeneral;
             for (int t = 0; t < fh.tiles; ++t) {
                 if (hm[4 * t + 1] == 0) continue;  // (the second tile of a group)
                 st.t0 = t; st.T = hm[4 * t + 1]; st.ws = hm[4 * t];

@@ -62,19 +62,30 @@ __device__ __forceinline__ v4i shr8(v4i v) { return v4i{v[0] >> 8, v[1] >> 8, v[
 // load(c) returns the data operand (A) of channel c, f = the tile's tap digits (B).  The four channels' chains
 // are written side by side: each MFMA's result is needed three MFMAs later, so the dependent shifts need no
 // s_nop padding.  SIGNED: clip to signed bytes (the horizontal pass, see clip8x4_signed).
-template <bool SIGNED, class Load>
+// DIGITS = 1: an axis that keeps its size (one tap of weight 1.0 = 2^22: the two low digits of every tap are zero, so
+// the chain collapses to its last link -- acc = (bias >> 16) + data x digit 2): the pass Pillow skips (Resample.c
+// ImagingResample: need_horizontal / need_vertical) costs one MFMA per channel, which is also the transposition the
+// operand layouts need, and no floor shifts.
+template <bool SIGNED, int DIGITS = 3, class Load>
 __device__ __forceinline__ void tile4(Load load, const v4i (&f)[3], v4i bias, uint32_t (&w)[4]) {
+    static_assert(DIGITS == 3 || DIGITS == 1, "digit chain: all three digits, or the last one alone");
     v4i a[4], acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) a[c] = load(c);
+    if (DIGITS == 1) {
+        const v4i b2 = v4i{bias[0] >> 16, bias[1] >> 16, bias[2] >> 16, bias[3] >> 16};  // ((bias >> 8) >> 8: floor shifts compose)
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
+        for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[c], f[2], b2, 0, 0, 0);
+    } else {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[c], f[d], d == 0 ? bias : acc[c], 0, 0, 0);
-        if (d < 2) {
+        for (int d = 0; d < 3; ++d) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = shr8(acc[c]);
+            for (int c = 0; c < 4; ++c)
+                acc[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[c], f[d], d == 0 ? bias : acc[c], 0, 0, 0);
+            if (d < 2) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] = shr8(acc[c]);
+            }
         }
     }
 #pragma unroll

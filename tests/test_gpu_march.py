@@ -195,3 +195,71 @@ def test_march_every_colour_alpha_pair(forced):
             marched += st["marched_layers"]
     assert lib.mic_atlas_destroy(atlas) == 0
     assert marched >= 8, marched
+
+
+@pytest.mark.parametrize("keeps", [1, 0])
+def test_lane_layers_that_keep_one_axis(keeps):
+    """A layer that keeps its width or its height (Pillow skips that pass: Resample.c need_horizontal / need_vertical; the
+    call site is compositor.py:20) runs the lane kernel's own instantiation for its class -- one MFMA per channel over the
+    kept axis instead of the three-digit chain -- in a launch of its own behind the general one.  Single layers,
+    transparent margins, and one call that mixes the three classes; MIC_RS_LANE_KEEPS=0 sends them all through the general
+    form.  Same pixels as the oracle either way."""
+    import torch
+    from image_transformation_amd import _native as nat
+    lib = nat.lib()
+    env = {"MIC_LAYER_CACHE_MB": "0", "MIC_RS_LANE_MIN_SLOTS": "0", "MIC_RS_LANE_KEEPS": str(keeps)}
+    os.environ.update(env)
+    try:
+        ctx = P()
+        assert lib.mic_create(torch.cuda.current_device(), ctypes.byref(ctx)) == 0, lib.mic_last_error()
+    finally:
+        for k in env:
+            del os.environ[k]
+    rng = np.random.default_rng(1234 + keeps)
+    shapes = [((300, 200), (300, 260)), ((300, 200), (390, 200)), ((513, 259), (513, 400)), ((130, 70), (260, 70)),
+              ((64, 64), (64, 100)), ((1000, 37), (1300, 37)), ((37, 1000), (37, 1300)), ((257, 255), (257, 140)),
+              ((255, 257), (131, 257)), ((17, 16), (17, 33)), ((16, 17), (31, 17)), ((640, 480), (640, 481)),
+              ((640, 480), (641, 480)), ((33, 900), (33, 899))]
+    marched = 0
+    for i, ((sw, sh), (dw, dh)) in enumerate(shapes):
+        src = _alpha(rng, rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8), i % 3)
+        if i % 4 == 3:  # a cutout with transparent margins: zero bands, tiles that only see zero bands
+            src[: sh // 3, :, 3] = 0
+            src[:, sw - sw // 4:, 3] = 0
+        objs = {5: src}
+        atlas = _atlas(lib, ctx, objs)
+        pl = [{"object_id": 5, "box": [0, 0, dw, dh]}]
+        for filt in (nat.LANCZOS, nat.BILINEAR):
+            for bg in ((0, 0, 0, 0), (9, 200, 33, 255)):
+                got, st = _composite(lib, ctx, nat, atlas, (dw, dh), bg, pl, filt)
+                b = np.empty((dh, dw, 4), np.uint8)
+                b[:] = bg
+                want = oracle.composite(b, objs, pl, filt)
+                assert np.array_equal(got, want), ((sw, sh), (dw, dh), filt, bg, st)
+                marched += st["marched_layers"]
+        assert lib.mic_atlas_destroy(atlas) == 0
+    assert marched >= 4 * (len(shapes) - 3), marched  # (the smallest ones stay with the tile kernel)
+    # the three classes in one call, boxes hanging over the canvas edges
+    objs = {i + 1: cases.synthetic.make_cutout(rng, int(rng.integers(40, 300)), int(rng.integers(30, 260)), ["binary", "soft"][i % 2])
+            for i in range(6)}
+    atlas = _atlas(lib, ctx, objs)
+    W, H = 1023, 517
+    pl = []
+    for k in range(18):
+        oid = 1 + k % 6
+        sh, sw = objs[oid].shape[:2]
+        w, h = int(sw * rng.uniform(0.6, 2.0)), int(sh * rng.uniform(0.6, 2.0))
+        if k % 3 == 1:
+            w = sw
+        elif k % 3 == 2:
+            h = sh
+        x1, y1 = int(rng.integers(-w // 2, W - w // 2)), int(rng.integers(-h // 2, H - h // 2))
+        pl.append({"object_id": oid, "box": [x1, y1, x1 + w, y1 + h]})
+    for filt in (nat.LANCZOS, nat.BILINEAR):
+        got, st = _composite(lib, ctx, nat, atlas, (W, H), (38, 73, 115, 255), pl, filt)
+        b = np.empty((H, W, 4), np.uint8)
+        b[:] = (38, 73, 115, 255)
+        assert np.array_equal(got, oracle.composite(b, objs, pl, filt)), (filt, st)
+        assert st["marched_layers"] == 18, st
+    assert lib.mic_atlas_destroy(atlas) == 0
+    assert lib.mic_destroy(ctx) == 0
