@@ -1,5 +1,7 @@
 #!/bin/bash
-# Round 5: chunk sizes by dispatch generation (MIC_LANE_AGE=w0,w1,w2,w3) -- events on the shipped build, stage stamps on the probe build
+# Round 5: chunk sizes by dispatch generation (MIC_LANE_AGE=w0,w1,w2,w3; needs profiles/r05_lane_age.patch in BOTH builds:
+#   scripts/build_variant.sh age -p profiles/r05_lane_age.patch; ... probe -p profiles/r05_lane_age.patch -p profiles/r05_lane_stage_probe.patch)
+# -- events on the patched build (MIC_LIB), stage stamps on the probe build
 set -u
 cd "${GRAFT_REPO_ROOT:?run through gpurun}" || exit 1
 out=gpurun_out/r05_lane_age
