@@ -39,6 +39,11 @@ while time.time() < t_end:
                 sw, sh = int(sw * rng.uniform(0.2, 2.5)), int(sh * rng.uniform(0.2, 2.5))
             elif r < 0.3:
                 sw, sh = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+            elif r < 0.4:  # one axis kept (the pass Pillow skips; the lane kernel's one-digit forms)
+                if rng.random() < 0.5:
+                    sw = int(sw * rng.uniform(0.5, 2.5))
+                else:
+                    sh = int(sh * rng.uniform(0.5, 2.5))
             x1, y1 = int(rng.integers(-sw - 2, W + 2)), int(rng.integers(-sh - 2, H + 2))
             pl.append({"object_id": oid, "box": [x1, y1, x1 + sw, y1 + sh]})
         kind = int(rng.integers(0, 3))
