@@ -24,7 +24,9 @@ int main() {
         for (int l = 0; l < n_layers; ++l) {
             const int sw = uni(20, 1400), sh = uni(20, 900);
             const double sc = 0.5 + (rng() % 1000) / 1000.0 * (trial % 5 == 0 ? 7.5 : 1.2);
-            const int dw = std::max(1, (int)(sw * sc)), dh = std::max(1, (int)(sh * sc));
+            int dw = std::max(1, (int)(sw * sc)), dh = std::max(1, (int)(sh * sc));
+            if (l % 5 == 1) dw = sw;  // a layer that keeps its width ...
+            if (l % 5 == 3) dh = sh;  // ... its height (lane_unit.h: piece classes)
             const int filter = (int)(rng() % 2);
             const mic::AxisTable th = sw == dw ? mic::identity_axis_table(sw) : mic::build_axis_table(sw, dw, filter);
             const mic::AxisTable tv = sh == dh ? mic::identity_axis_table(sh) : mic::build_axis_table(sh, dh, filter);
@@ -35,6 +37,7 @@ int main() {
             if (fh.max_chunks != 1 || fv.max_chunks != 1) continue;  // (the layer would go to the tile kernel)
             mic::LaneStrip st{};
             st.sh = sh; st.dw = dw; st.dh = dh;
+            st.cls = sw == dw ? mic::kLaneKeepsWidth : sh == dh ? mic::kLaneKeepsHeight : mic::kLaneGeneral;
             st.tiled_ct = (sw + 15) / 16 + 3;
             st.tiled_src = next_addr; next_addr += (uint64_t)4 * ((sh + 15) / 16) * st.tiled_ct * 256 + 4096;
             st.dst = next_addr; next_addr += (uint64_t)dw * dh * 4 + 4096;
@@ -76,7 +79,7 @@ int main() {
                     if (it == by_key.end()) { fprintf(stderr, "a record of no strip\n"); return 4; }
                     const mic::LaneStrip &s = *it->second;
                     const int y0 = u.row0 / 16, y1 = y0 + u.n_vtiles;
-                    if (u.row0 % 16 || y0 < 0 || y1 > s.ty || u.T != s.T || u.dw != s.dw || u.dh != s.dh) { fprintf(stderr, "geometry\n"); return 5; }
+                    if (u.row0 % 16 || y0 < 0 || y1 > s.ty || u.T != s.T || u.dw != s.dw || u.dh != s.dh || u.cls != s.cls) { fprintf(stderr, "geometry\n"); return 5; }
                     if (u.band0 != (s.vm[4 * y0] >> 4) || u.band_last != (s.vm[4 * (y1 - 1) + 1] & 0xFFFFFF) || u.band0 > u.band_last ||
                         u.band_last >= (s.sh + 15) / 16) { fprintf(stderr, "bands\n"); return 6; }
                     if (u.vfrag != s.vfrag + (uint64_t)y0 * 3072 || u.vbias != s.vbias + (uint64_t)y0 * 64 || u.vemit != s.vmeta + ((uint64_t)4 * y0 + 1) * 4 ||
