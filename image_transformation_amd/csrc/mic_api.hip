@@ -220,6 +220,7 @@ struct mic_ctx {
     bool lane_on = true;
     int lane_min_slots = 256, lane_max_slots = 1 << 20;  // (the reference-sized call, 4 cutouts of ~0.02 Mpx: 67 us of wall through the tile kernel, 80 through this one)
     double lane_chunk = 15000;  // MIC_RS_LANE_CHUNK: least cost (shader cycles of the model in lane_partition) of one slot's pieces
+    double lane_split_slots = 1500, lane_split_chunk = 9000;  // MIC_RS_LANE_SPLIT=<slots>,<chunk>: calls below <slots> slots of work run one x-tile per piece, cut at <chunk> (0,0: never)
     uint32_t *median_scratch = nullptr;  // device: two sets of histogram slots (a double buffer) + kMedianMaxBatch result words
     MedianState median_state;            // which half the next call works in, what the previous one left to clear
     bool layer_args = true;              // MIC_LAYER_ARGS=0: single-canvas launches read their layer records from the device table
@@ -332,6 +333,13 @@ extern "C" int mic_create(int device, mic_ctx **out) {
     if (const char *ln = getenv("MIC_RS_LANE_MIN_SLOTS")) ctx->lane_min_slots = std::max(0, atoi(ln));
     if (const char *ln = getenv("MIC_RS_LANE_SLOTS")) ctx->lane_max_slots = std::min(1 << 20, std::max(32, atoi(ln) / 32 * 32));
     if (const char *ln = getenv("MIC_RS_LANE_CHUNK")) ctx->lane_chunk = std::max(5000.0, atof(ln));
+    if (const char *ls = getenv("MIC_RS_LANE_SPLIT")) {
+        double a = 0, b = 0;
+        if (sscanf(ls, "%lf,%lf", &a, &b) == 2) {
+            ctx->lane_split_slots = std::max(0.0, a);
+            ctx->lane_split_chunk = std::max(5000.0, b);
+        }
+    }
     for (auto &s : ctx->slots) {
         e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
         if (e != hipSuccess) {
@@ -1092,8 +1100,27 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
         }
     }
     if (!strips.empty()) {
+        double chunk = ctx->lane_chunk;
+        // A call well below one round of wave slots runs every x-tile as a piece of its own (T = 1: twice the waves, each
+        // with half the arithmetic per band, cut finer): a lone wave per SIMD runs the digit chains at half speed
+        // (profiles/r05_lane_stage_probe.txt), and with so few waves the shared window loads are not what costs.  4 layers of
+        // 250 - 500 px: 9.7 -> 7.6, 11.0 -> 9.7, 13.2 -> 11.9 us; from ~1500 slots up the longer dispatch ramp takes the gain
+        // back (profiles/r05_small_calls.txt).  The tables are the same: tile j of a group uses the group's window.
+        double total = 0;
+        for (const LaneStrip &st : strips) total += lane_piece_cost(st.vm, st.T, 0, st.ty);
+        if (total < ctx->lane_split_slots * ctx->lane_chunk) {
+            std::vector<LaneStrip> one;
+            one.reserve(2 * strips.size());
+            for (LaneStrip st : strips) {
+                const int T = st.T;
+                st.T = 1;
+                for (int j = 0; j < T; ++j, ++st.t0) one.push_back(st);
+            }
+            strips.swap(one);
+            chunk = ctx->lane_split_chunk;
+        }
         LaneCut cut;
-        lane_partition(strips, ctx->lane_chunk, ctx->lane_max_slots, &cut);
+        lane_partition(strips, chunk, ctx->lane_max_slots, &cut);
         pt->lane.swap(cut.records);
         pt->lane_slots = cut.slots;
     }

@@ -22,7 +22,7 @@ import oracle  # noqa: E402  (the checker)
 P = ctypes.c_void_p
 
 
-@pytest.fixture(scope="module", params=["lane", "march"])
+@pytest.fixture(scope="module", params=["lane", "lane_two_tiles", "march"])
 def forced(request):
     import torch
     if not torch.cuda.is_available():
@@ -30,7 +30,11 @@ def forced(request):
     from image_transformation_amd import _native
     lib = _native.lib()
     env = {"MIC_LAYER_CACHE_MB": "0"}  # every call resamples (a resident layer of an earlier call would skip the kernel under test)
-    env.update({"MIC_RS_LANE_MIN_SLOTS": "0"} if request.param == "lane" else {"MIC_RS_LANE": "0", "MIC_RS_MARCH_MIN_UNITS": "0"})
+    # (calls below 1500 slots of work run one x-tile per piece: "lane_two_tiles" switches that off, so that these small
+    # shapes also reach the two-tile form the big calls use)
+    env.update({"MIC_RS_LANE_MIN_SLOTS": "0"} if request.param == "lane" else
+               {"MIC_RS_LANE_MIN_SLOTS": "0", "MIC_RS_LANE_SPLIT": "0,0"} if request.param == "lane_two_tiles" else
+               {"MIC_RS_LANE": "0", "MIC_RS_MARCH_MIN_UNITS": "0"})
     os.environ.update(env)
     try:
         ctx = P()
@@ -38,7 +42,7 @@ def forced(request):
     finally:
         for k in env:
             del os.environ[k]
-    _native.kernel_under_test = request.param
+    _native.kernel_under_test = "march" if request.param == "march" else "lane"
     yield lib, ctx, _native
     assert lib.mic_destroy(ctx) == 0
 
@@ -197,8 +201,8 @@ def test_march_every_colour_alpha_pair(forced):
     assert marched >= 8, marched
 
 
-@pytest.mark.parametrize("keeps", [1, 0])
-def test_lane_layers_that_keep_one_axis(keeps):
+@pytest.mark.parametrize("keeps,two_tiles", [(1, False), (1, True), (0, False)])
+def test_lane_layers_that_keep_one_axis(keeps, two_tiles):
     """A layer that keeps its width or its height (Pillow skips that pass: Resample.c need_horizontal / need_vertical; the
     call site is compositor.py:20) runs the lane kernel's own instantiation for its class -- one MFMA per channel over the
     kept axis instead of the three-digit chain -- in a launch of its own behind the general one.  Single layers,
@@ -208,6 +212,8 @@ def test_lane_layers_that_keep_one_axis(keeps):
     from image_transformation_amd import _native as nat
     lib = nat.lib()
     env = {"MIC_LAYER_CACHE_MB": "0", "MIC_RS_LANE_MIN_SLOTS": "0", "MIC_RS_LANE_KEEPS": str(keeps)}
+    if two_tiles:  # (small calls run one x-tile per piece; this sends them through the two-tile bodies as well)
+        env["MIC_RS_LANE_SPLIT"] = "0,0"
     os.environ.update(env)
     try:
         ctx = P()
