@@ -225,6 +225,7 @@ struct mic_ctx {
     MedianState median_state;            // which half the next call works in, what the previous one left to clear
     bool layer_args = true;              // MIC_LAYER_ARGS=0: single-canvas launches read their layer records from the device table
     bool tile_args = true;               // MIC_RS_TILE_ARGS=0: the tile kernel always reads its entries from the device table
+    int64_t tile_small_px = 1 << 20;     // MIC_RS_TILE_SMALL_PX: calls that resize fewer output pixels than this take 32 x 32 tiles first (0: never)
     bool lane_keeps = true;              // MIC_RS_LANE_KEEPS=0: layers that keep one axis run the general lane kernel
     int median_two_launches = -1;        // MIC_MEDIAN_TWO_LAUNCHES=1 / 0: force the two-launch / one-launch median (-1: by image size)
     uint32_t *gradient_table = nullptr;  // device: fill_gradient's per-position colours (allocated on first use)
@@ -350,6 +351,7 @@ extern "C" int mic_create(int device, mic_ctx **out) {
     tick("8 events");
     if (const char *la = getenv("MIC_LAYER_ARGS")) ctx->layer_args = atoi(la) != 0;
     if (const char *ta = getenv("MIC_RS_TILE_ARGS")) ctx->tile_args = atoi(ta) != 0;
+    if (const char *sp = getenv("MIC_RS_TILE_SMALL_PX")) ctx->tile_small_px = std::max(0ll, atoll(sp));
     if (const char *lk = getenv("MIC_RS_LANE_KEEPS")) ctx->lane_keeps = atoi(lk) != 0;
     if (const char *v = getenv("MIC_LAYER_CACHE_MB")) ctx->layer_cache_cap = (size_t)std::max(0ll, atoll(v)) << 20;
     if (const char *tl = getenv("MIC_MEDIAN_TWO_LAUNCHES")) ctx->median_two_launches = atoi(tl) != 0 ? 1 : 0;
@@ -888,11 +890,16 @@ int window_needed(const std::vector<int32_t> &meta, int tiles, int per) {
 // Pick the workgroup tile of the tile kernel for one layer: the biggest of a short list whose source planes +
 // intermediate planes fit LDS, preferring sizes that let three workgroups share a CU.  Leaves tx16 == 0 when
 // nothing fits (extreme shrinks: the two-pass kernels take those).
-int choose_tile(mic_ctx *ctx, ResizePlan *p, int filter, hipStream_t stream) {
+// small_call: the whole call resizes less than ~1 Mpx, i.e. has fewer tiles of 64 x 64 than the chip has CUs -- then tiles
+// of 32 x 32 first: four times the workgroups, each with a quarter of the passes between its barriers (a small launch is
+// as long as its longest workgroup: 4 layers of 100 - 250 px 10.4 - 11.3 -> 7.9 - 9.3 us, the reference-sized call 61.5 ->
+// 58.9 us of wall; from 1 Mpx up the bigger tile's shared halo wins again.  profiles/r05_small_calls.txt table 6).
+int choose_tile(mic_ctx *ctx, ResizePlan *p, int filter, hipStream_t stream, bool small_call = false) {
     FragEntry fh, fv;
     if (int rc = get_frags(ctx, p->sw, p->dw, filter, stream, &fh)) return rc;
     if (int rc = get_frags(ctx, p->sh, p->dh, filter, stream, &fv)) return rc;
-    static const int kTiles[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}};
+    static const int kBig[][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}, {1, 1}}, kSmall[][2] = {{2, 2}, {2, 1}, {1, 1}, {4, 2}, {4, 4}};
+    const int (*kTiles)[2] = small_call ? kSmall : kBig;
     p->tx16 = 0;
     if ((int64_t)p->sw * p->sh < 4) return MIC_OK;  // the kernel's 16-byte loads need 4 pixels to clamp into
     if ((int64_t)p->sw * p->sh >= ((int64_t)1 << 30)) return MIC_OK;  // its 32-bit pixel index steps past the end
@@ -903,7 +910,7 @@ int choose_tile(mic_ctx *ctx, ResizePlan *p, int filter, hipStream_t stream) {
     for (const bool banded : {false, true}) {
         for (const size_t cap : {kRsTilePreferredLds, kRsTileMaxLds}) {
             for (int ti = 0; ti < 5; ++ti) {
-                const auto &t = kTiles[banded ? 4 - ti : ti];
+                const auto &t = banded ? kBig[4 - ti] : kTiles[ti];
                 // Pitches cover what a tile needs, not what its 64-sample chunks touch: a read past the end of a
                 // row lands in the next row (or in the slack after the last one) and meets zero tap digits.
                 const int pitch_c = round16(window_needed(*fh.meta_host, fh.tiles, t[0]));
@@ -1398,9 +1405,10 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
     // Is this a call for the lane kernel?  Decided up front on the boxes alone (the same estimate the routing below
     // confirms with the tables in hand), because it says which FORM of the axis tables to build: the lane forms for such
     // a call, the tile forms otherwise -- never both for the same never-seen box size (a table is ~60 us of sin()).
-    bool lane_call = false;
-    if (ctx->lane_on) {
+    bool lane_call = false, small_call = false;
+    {
         double cost = 0;
+        int64_t out_px = 0;
         for (int ji = 0; ji < n_jobs; ++ji) {
             const mic_job &J = jobs[ji];
             if (J.n_placements <= 0 || !J.placements) continue;
@@ -1414,9 +1422,11 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                 const int64_t w = std::max<int64_t>(1, (int64_t)Pl.box[2] - Pl.box[0]), h = std::max<int64_t>(1, (int64_t)Pl.box[3] - Pl.box[1]);
                 if ((w == E.w && h == E.h) || w > kMaxDim || h > kMaxDim) continue;
                 cost += lane_layer_cost(E.h, (int)w, (int)h);  // (a box placed twice counts twice: an estimate)
+                out_px += w * h;
             }
         }
-        lane_call = cost >= ctx->lane_chunk * std::max(1, ctx->lane_min_slots);
+        lane_call = ctx->lane_on && cost >= ctx->lane_chunk * std::max(1, ctx->lane_min_slots);
+        small_call = out_px < ctx->tile_small_px;
     }
     {   // the axis tables of this call's resized boxes that the context has not seen yet, built ahead on several threads
         std::vector<CoefKey> need;
@@ -1508,7 +1518,7 @@ static int plan_build(mic_ctx *ctx, int n_atlases, mic_atlas *const *atlases, in
                         if (int rc = choose_lane(ctx, &rp, filter, stream)) return rc;
                     if (!rp.lane_ok) {  // (a layer the lane kernel does not take, or a small call: the tile forms)
                         if (int rc = choose_march(ctx, &rp, filter, stream)) return rc;
-                        if (int rc = choose_tile(ctx, &rp, filter, stream)) return rc;
+                        if (int rc = choose_tile(ctx, &rp, filter, stream, small_call)) return rc;
                     }
                     plan_idx = plans.size();
                     plans.push_back(rp);
@@ -2132,7 +2142,7 @@ extern "C" int mic_resize(mic_ctx *ctx, const void *src_dev, int32_t src_w, int3
     rp.dst_ptr = reinterpret_cast<uint64_t>(dst_dev);
     // a single image: the tile kernel (it premultiplies and planarises the window while loading it; the marching
     // kernel would first need a planar copy of the whole source, and one image rarely fills the chip with its units)
-    if (int rc = choose_tile(ctx, &rp, filter, stream)) return rc;
+    if (int rc = choose_tile(ctx, &rp, filter, stream, (int64_t)dst_w * dst_h < ctx->tile_small_px)) return rc;
     size_t need = 0;
     if (rp.tx16 == 0 && dst_w != src_w && dst_h != src_h) need = (size_t)dst_w * src_h * 4 + kGuard;
     if (int rc = ensure_arena(ctx, need)) return rc;

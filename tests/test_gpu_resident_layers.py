@@ -15,7 +15,7 @@ import cases  # noqa: E402
 import oracle  # noqa: E402
 
 P = ctypes.c_void_p
-KNOBS = ("MIC_RS_MARCH_MIN_UNITS", "MIC_LAYER_CACHE_MB", "MIC_RS_LANE", "MIC_RS_LANE_MIN_SLOTS", "MIC_RS_TILE_ARGS")
+KNOBS = ("MIC_RS_MARCH_MIN_UNITS", "MIC_LAYER_CACHE_MB", "MIC_RS_LANE", "MIC_RS_LANE_MIN_SLOTS", "MIC_RS_TILE_ARGS", "MIC_RS_TILE_SMALL_PX")
 # which resample kernel a context routes qualifying layers to (mic_api.hip: routing)
 ROUTES = {"tile": {"MIC_RS_LANE": 0}, "march": {"MIC_RS_LANE": 0, "MIC_RS_MARCH_MIN_UNITS": 0}, "lane": {"MIC_RS_LANE_MIN_SLOTS": 0}}
 
@@ -237,4 +237,40 @@ def test_tile_entries_in_kernel_arguments_boundary(in_args, monkeypatch):
         torch.cuda.synchronize()
         assert np.array_equal(dst.cpu().numpy(), oracle.resize(src, (dw, dh))), (dw, dh)
     del atlas
+    assert lib.mic_destroy(ctx.handle) == 0
+
+
+@pytest.mark.parametrize("small_px", [0, 1 << 30])
+def test_tile_sizes_of_small_and_big_calls(small_px, monkeypatch):
+    """The tile kernel's workgroup tile: 64 x 64 outputs, or 32 x 32 for calls that resize less than ~1 Mpx in all (four
+    times the workgroups on a chip the call cannot fill anyway; MIC_RS_TILE_SMALL_PX).  The same shapes with the small tile
+    forced on everything (1 << 30) and off (0): composites of several resized layers and single images through mic_resize,
+    both filters, equal to the oracle."""
+    import torch
+    from image_transformation_amd import _native
+    from image_transformation_amd.compositor import Atlas, SolidCanvas, composite_device, coerce_placements
+    ctx = _ctx(monkeypatch, MIC_RS_LANE=0, MIC_RS_TILE_SMALL_PX=small_px, MIC_LAYER_CACHE_MB=0)
+    lib = _native.lib()
+    rng = np.random.default_rng(3232 + (small_px > 0))
+    W, H = 900, 600
+    bg = np.empty((H, W, 4), np.uint8)
+    bg[:] = (9, 200, 33, 255)
+    cv = SolidCanvas((W, H), (9, 200, 33, 255))
+    for n_obj, n_layers in ((3, 4), (6, 11)):
+        objs, pl = _scene(rng, n_obj, W, H, n_layers)
+        atlas = Atlas(objs, ctx=ctx)
+        for filt in (0, 1):
+            got = composite_device(atlas, [cv], [coerce_placements(atlas, pl)], filter=filt)[0].cpu().numpy()
+            assert np.array_equal(got, oracle.composite(bg, objs, pl, filt)), (n_obj, n_layers, filt)
+            assert ctx.stats()["marched_layers"] == 0
+        del atlas
+    for (sw, sh), (dw, dh) in (((90, 70), (108, 84)), ((301, 203), (457, 311)), ((457, 311), (301, 203)), ((1300, 900), (1500, 1100)),
+                               ((33, 47), (31, 200)), ((640, 480), (96, 72)), ((19, 23), (640, 480)), ((1, 7), (50, 3))):
+        src = cases.synthetic.make_cutout(rng, sw, sh, "soft")
+        dev = torch.from_numpy(src).cuda()
+        for filt in (0, 1):
+            dst = torch.empty((dh, dw, 4), dtype=torch.uint8, device="cuda")
+            _native.check(lib.mic_resize(ctx.handle, P(dev.data_ptr()), sw, sh, P(dst.data_ptr()), dw, dh, filt, P(ctx.stream_ptr())))
+            torch.cuda.synchronize()
+            assert np.array_equal(dst.cpu().numpy(), oracle.resize(src, (dw, dh), filt)), ((sw, sh), (dw, dh), filt)
     assert lib.mic_destroy(ctx.handle) == 0
