@@ -220,7 +220,7 @@ struct mic_ctx {
     bool lane_on = true;
     int lane_min_slots = 256, lane_max_slots = 1 << 20;  // (the reference-sized call, 4 cutouts of ~0.02 Mpx: 67 us of wall through the tile kernel, 80 through this one)
     double lane_chunk = 15000;  // MIC_RS_LANE_CHUNK: least cost (shader cycles of the model in lane_partition) of one slot's pieces
-    double lane_split_slots = 1500, lane_split_chunk = 9000;  // MIC_RS_LANE_SPLIT=<slots>,<chunk>: calls below <slots> slots of work run one x-tile per piece, cut at <chunk> (0,0: never)
+    double lane_split_slots = 4096, lane_split_chunk = 9000;  // MIC_RS_LANE_SPLIT=<slots>,<chunk>: calls below <slots> slots of work (one round) run one x-tile per piece, cut at <chunk> or more (0,0: never)
     uint32_t *median_scratch = nullptr;  // device: two sets of histogram slots (a double buffer) + kMedianMaxBatch result words
     MedianState median_state;            // which half the next call works in, what the previous one left to clear
     bool layer_args = true;              // MIC_LAYER_ARGS=0: single-canvas launches read their layer records from the device table
@@ -1108,13 +1108,20 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
     }
     if (!strips.empty()) {
         double chunk = ctx->lane_chunk;
-        // A call well below one round of wave slots runs every x-tile as a piece of its own (T = 1: twice the waves, each
-        // with half the arithmetic per band, cut finer): a lone wave per SIMD runs the digit chains at half speed
+        // A call below one round of wave slots runs every x-tile as a piece of its own (T = 1: twice the waves, each with
+        // half the arithmetic per band): a lone wave per SIMD runs the digit chains at half speed
         // (profiles/r05_lane_stage_probe.txt), and with so few waves the shared window loads are not what costs.  4 layers of
-        // 250 - 500 px: 9.7 -> 7.6, 11.0 -> 9.7, 13.2 -> 11.9 us; from ~1500 slots up the longer dispatch ramp takes the gain
-        // back (profiles/r05_small_calls.txt).  The tables are the same: tile j of a group uses the group's window.
-        double total = 0;
-        for (const LaneStrip &st : strips) total += lane_piece_cost(st.vm, st.T, 0, st.ty);
+        // 250 - 500 px: 9.7 -> 7.6, 11.0 -> 9.7, 13.2 -> 11.9 us; level from ~1500 slots up (the dispatch ramp of twice the
+        // waves), never worse below a round (profiles/r05_small_calls.txt).  The tables are the same: tile j of a group
+        // uses the group's window.  Such pieces are cut at 9 K cycles -- longer for upscales, where one band of source rows
+        // feeds several tiles of output rows and a cut inside that run repeats the band's horizontal pass (C5's x8
+        // upscales: 19.2 -> 17.5 us at 40 K).
+        double total = 0, bands = 0, rows = 0;
+        for (const LaneStrip &st : strips) {
+            total += lane_piece_cost(st.vm, st.T, 0, st.ty);
+            bands += (st.sh + 15) / 16;
+            rows += st.ty;
+        }
         if (total < ctx->lane_split_slots * ctx->lane_chunk) {
             std::vector<LaneStrip> one;
             one.reserve(2 * strips.size());
@@ -1124,7 +1131,7 @@ int plan_passes(mic_ctx *ctx, const std::vector<ResizePlan> &plans, int filter, 
                 for (int j = 0; j < T; ++j, ++st.t0) one.push_back(st);
             }
             strips.swap(one);
-            chunk = ctx->lane_split_chunk;
+            chunk = std::min(40000.0, std::max(ctx->lane_split_chunk, 5000.0 * rows / std::max(1.0, bands)));
         }
         LaneCut cut;
         lane_partition(strips, chunk, ctx->lane_max_slots, &cut);
