@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <tuple>
 #include <vector>
 
 #include "lane_unit.h"
@@ -70,6 +71,7 @@ inline void lane_partition(const std::vector<LaneStrip> &strips, double chunk_co
     // source columns and taps through the XCD's L2) run together.  profiles/r05_lane_kernel.txt.
     constexpr int kRound = 4096;
     double n = total / chunk_cost;
+    const bool whole_rounds = n > kRound;
     if (n > kRound) n = kRound * std::max(1.0, std::floor(total / (kRound * 55000.0) + 0.5));
     int n_slots = (int)std::min<double>(max_slots, std::max(32.0, n));
     // (whole workgroups, eight at a time; rounded UP: a call of 56 slots of work cut into 32 chunks gave every strip a chunk and a
@@ -148,9 +150,27 @@ inline void lane_partition(const std::vector<LaneStrip> &strips, double chunk_co
     dealt.reserve((size_t)slots + lane.size() - (size_t)chunks + 8);
     const int n_wg = slots / 4, per = n_wg / 8;
     static const bool in_order = [] { const char *e = getenv("MIC_RS_LANE_XCDMAP"); return e && atoi(e) == 0; }();  // (A/B: chunk c -> slot c)
-    for (int c = 0; c < slots; ++c) {
-        const int k = c / (4 * per), j = c % (4 * per);
-        const size_t slot = in_order ? (size_t)c : (size_t)(4 * (8 * (j / 4) + k) + (j % 4));
+    // Launches of whole rounds deal their chunks in the order (layer, rows, columns) rather than the order of the cut (layer,
+    // columns, rows): pieces side by side in x become neighbours in the sequence.  The fabric bytes do not move (98.1 -> 97.4
+    // MB: the shared halves of the windows were L2 hits already); binary-alpha cutouts gain 3.7 % (35.0 -> 33.7 us: their
+    // all-transparent top and bottom pieces, which skip the arithmetic, no longer share a workgroup with full ones), soft
+    // alpha and the batch are level; calls below a round lose 4 % and keep the cut's order.  MIC_LANE_ORDER=0: always the cut's.
+    static const bool by_rows = [] { const char *e = getenv("MIC_LANE_ORDER"); return !e || atoi(e) != 0; }();
+    std::vector<int> order((size_t)slots);
+    for (int c = 0; c < slots; ++c) order[(size_t)c] = c;
+    if (by_rows && whole_rounds) {
+        auto key = [&](int c) {
+            const uint32_t b0 = first[(size_t)c];
+            if (b0 == first[(size_t)c + 1]) return std::make_tuple(~uint64_t(0), 0, 0);  // (empty slots last)
+            const RsLaneUnit &u = lane[b0];
+            return std::make_tuple(u.dst, u.row0, u.x0);
+        };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key(a) < key(b); });
+    }
+    for (int ci = 0; ci < slots; ++ci) {
+        const int c = order[(size_t)ci];
+        const int k = ci / (4 * per), j = ci % (4 * per);
+        const size_t slot = in_order ? (size_t)ci : (size_t)(4 * (8 * (j / 4) + k) + (j % 4));
         const uint32_t b0 = first[(size_t)c], b1 = first[(size_t)c + 1];
         if (b0 == b1) continue;  // (an empty slot: the zero record, n_vtiles == 0)
         dealt[slot] = lane[b0];
